@@ -1,0 +1,816 @@
+// engine.cpp -- host side of libsymmicp: the C-ABI of include/symmicp.h.
+//
+// Host C++ owns control flow and the 6x6 / 3x3 solve (host_solve.cpp); the GPU owns
+// every O(N) pass (kernels_pass.hip) and the one-time index build (kernels_build.hip).
+// Per iteration of the reference loop (ICP/myicp.cpp:123-142) the host does:
+//   solve(last sums) -> 4x4 increment -> launch ONE fused pass kernel + a 1-block final
+//   reduce -> [RCCL all-reduce of 40 doubles when sharded] -> read 40 doubles -> repeat.
+// There is no CPU fallback: without a HIP device every entry point fails loudly.
+#include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "symmicp.h"
+#include "symmicp_internal.h"
+#include "host_solve.h"
+
+using namespace symmicp;
+
+// ---- RCCL, loaded lazily (single-GPU users never touch it) ---------------------
+namespace {
+typedef struct { char internal[128]; } rcclUniqueId;
+typedef void *rcclComm_t;
+typedef int (*fn_ncclGetUniqueId)(rcclUniqueId *);
+typedef int (*fn_ncclCommInitRank)(rcclComm_t *, int, rcclUniqueId, int);
+typedef int (*fn_ncclCommDestroy)(rcclComm_t);
+typedef int (*fn_ncclAllReduce)(const void *, void *, size_t, int, int, rcclComm_t, hipStream_t);
+typedef const char *(*fn_ncclGetErrorString)(int);
+constexpr int kNcclFloat64 = 8;   // ncclDouble (rccl.h ncclDataType_t)
+constexpr int kNcclSum = 0;       // ncclSum
+
+struct Rccl {
+    void *handle = nullptr;
+    fn_ncclGetUniqueId GetUniqueId = nullptr;
+    fn_ncclCommInitRank CommInitRank = nullptr;
+    fn_ncclCommDestroy CommDestroy = nullptr;
+    fn_ncclAllReduce AllReduce = nullptr;
+    fn_ncclGetErrorString GetErrorString = nullptr;
+    std::string err;
+    bool load()
+    {
+        if (handle) return true;
+        // prefer an RCCL already mapped into the process (e.g. the copy torch links against)
+        const char *names[] = {"librccl.so.1", "librccl.so"};
+        for (const char *nm : names) { handle = dlopen(nm, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL); if (handle) break; }
+        if (!handle)
+            for (const char *nm : names) { handle = dlopen(nm, RTLD_NOW | RTLD_GLOBAL); if (handle) break; }
+        if (!handle) { err = std::string("cannot load librccl: ") + dlerror(); return false; }
+        GetUniqueId = (fn_ncclGetUniqueId)dlsym(handle, "ncclGetUniqueId");
+        CommInitRank = (fn_ncclCommInitRank)dlsym(handle, "ncclCommInitRank");
+        CommDestroy = (fn_ncclCommDestroy)dlsym(handle, "ncclCommDestroy");
+        AllReduce = (fn_ncclAllReduce)dlsym(handle, "ncclAllReduce");
+        GetErrorString = (fn_ncclGetErrorString)dlsym(handle, "ncclGetErrorString");
+        if (!GetUniqueId || !CommInitRank || !CommDestroy || !AllReduce) { err = "librccl misses nccl* symbols"; return false; }
+        return true;
+    }
+};
+Rccl g_rccl;
+
+double now_s()
+{
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+}  // namespace
+
+struct symmicp_ctx {
+    symmicp_config cfg{};
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    // communicator
+    int nranks = 1, rank = 0;
+    rcclComm_t comm = nullptr;
+    // target
+    uint32_t n_t = 0;
+    float *tgt_block = nullptr;      // 6 planar arrays
+    CloudSoA tgt{};
+    float4 *tq = nullptr, *tn = nullptr;
+    float4 *boxes = nullptr;
+    uint2 *cells = nullptr;
+    TargetIndex ix{};
+    bool have_index = false;
+    float pivot[3] = {0, 0, 0};
+    // source share
+    uint32_t n_s_total = 0, n_loc = 0, src_off = 0;
+    float *src0_block = nullptr, *cur_block = nullptr;
+    CloudSoA src0{}, cur{};
+    uint32_t *src_order = nullptr;   // share position -> row in the caller's cloud (null = identity)
+    int32_t *pos = nullptr;
+    float *d2 = nullptr;
+    unsigned long long *best64 = nullptr;
+    // reduction
+    int pass_blocks = 0;
+    double *partials = nullptr, *d_sums = nullptr, *h_sums = nullptr, *h_sums_dev = nullptr;
+    // loop state
+    bool begun = false;
+    int iters = 0;
+    float X[16];
+    symmicp_sums last{};
+    // stats
+    bool timing = false;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    symmicp_stats st{};
+};
+
+#define HIP_TRY(ctx, call)                                                                                  \
+    do {                                                                                                    \
+        hipError_t e__ = (call);                                                                            \
+        if (e__ != hipSuccess) {                                                                            \
+            (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e__);                                \
+            return SYMMICP_ERR_HIP;                                                                         \
+        }                                                                                                   \
+    } while (0)
+
+static int fail(symmicp_ctx *c, int code, const std::string &msg)
+{
+    if (c) c->err = msg;
+    return code;
+}
+
+static void soa_from_block(float *block, size_t n, CloudSoA &s)
+{
+    s.x = block; s.y = block + n; s.z = block + 2 * n; s.nx = block + 3 * n; s.ny = block + 4 * n; s.nz = block + 5 * n;
+}
+
+static void identity16(float X[16])
+{
+    for (int k = 0; k < 16; k++) X[k] = (k % 5 == 0) ? 1.f : 0.f;
+}
+
+static int resolved_apply(const symmicp_config &c)
+{
+    if (c.apply == SYMMICP_APPLY_INCREMENTAL || c.apply == SYMMICP_APPLY_CUMULATIVE) return c.apply;
+    return c.mode == SYMMICP_MODE_QUIRKS ? SYMMICP_APPLY_INCREMENTAL : SYMMICP_APPLY_CUMULATIVE;
+}
+
+extern "C" {
+
+int symmicp_version(void) { return 100; }
+
+void symmicp_config_default(symmicp_config *cfg)
+{
+    if (!cfg) return;
+    std::memset(cfg, 0, sizeof(*cfg));
+    cfg->struct_size = (int32_t)sizeof(*cfg);
+    cfg->device = -1;
+    cfg->mode = SYMMICP_MODE_QUIRKS;
+    cfg->corr = SYMMICP_CORR_IDENTITY;
+    cfg->apply = SYMMICP_APPLY_DEFAULT;
+    cfg->max_iters = 10;            // myicp.cpp:6
+    cfg->diff_threshold = 1.0f;     // myicp.cpp:6
+    cfg->max_corr_dist = 0.f;
+    cfg->fixed_iters = 0;
+    cfg->sort_source = 1;
+    cfg->verbose = 0;
+}
+
+static int check_cfg(const symmicp_config *cfg)
+{
+    if (!cfg || cfg->struct_size != (int32_t)sizeof(symmicp_config)) return SYMMICP_ERR_ARG;
+    if (cfg->mode != SYMMICP_MODE_QUIRKS && cfg->mode != SYMMICP_MODE_PAPER) return SYMMICP_ERR_ARG;
+    if (cfg->corr < SYMMICP_CORR_IDENTITY || cfg->corr > SYMMICP_CORR_TREE) return SYMMICP_ERR_ARG;
+    if (cfg->apply < SYMMICP_APPLY_DEFAULT || cfg->apply > SYMMICP_APPLY_CUMULATIVE) return SYMMICP_ERR_ARG;
+    if (cfg->max_iters < 0) return SYMMICP_ERR_ARG;
+    return SYMMICP_OK;
+}
+
+int symmicp_create(const symmicp_config *cfg, symmicp_ctx **out)
+{
+    if (!out) return SYMMICP_ERR_ARG;
+    *out = nullptr;
+    if (check_cfg(cfg) != SYMMICP_OK) return SYMMICP_ERR_ARG;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return SYMMICP_ERR_HIP;   // no CPU fallback
+    symmicp_ctx *c = new symmicp_ctx();
+    c->cfg = *cfg;
+    if (cfg->device >= 0) {
+        if (cfg->device >= ndev || hipSetDevice(cfg->device) != hipSuccess) { delete c; return SYMMICP_ERR_HIP; }
+        c->device = cfg->device;
+    } else if (hipGetDevice(&c->device) != hipSuccess) { delete c; return SYMMICP_ERR_HIP; }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, c->device) != hipSuccess) { delete c; return SYMMICP_ERR_HIP; }
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0 && !std::getenv("SYMMICP_ALLOW_ANY_ARCH")) {
+        // the code object only carries gfx950 ISA
+        delete c;
+        return SYMMICP_ERR_HIP;
+    }
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return SYMMICP_ERR_HIP; }
+    bool ok = hipMalloc((void **)&c->partials, sizeof(double) * kNSum * 8192) == hipSuccess &&
+              hipMalloc((void **)&c->d_sums, sizeof(double) * kNSum) == hipSuccess &&
+              hipHostMalloc((void **)&c->h_sums, sizeof(double) * kNSum, hipHostMallocMapped) == hipSuccess &&
+              hipHostGetDevicePointer((void **)&c->h_sums_dev, c->h_sums, 0) == hipSuccess &&
+              hipEventCreate(&c->ev0) == hipSuccess && hipEventCreate(&c->ev1) == hipSuccess;
+    if (!ok) { symmicp_destroy(c); return SYMMICP_ERR_HIP; }
+    identity16(c->X);
+    *out = c;
+    return SYMMICP_OK;
+}
+
+static void free_target(symmicp_ctx *c)
+{
+    hipFree(c->tgt_block); hipFree(c->tq); hipFree(c->tn); hipFree(c->boxes); hipFree(c->cells);
+    c->tgt_block = nullptr; c->tq = nullptr; c->tn = nullptr; c->boxes = nullptr; c->cells = nullptr;
+    c->have_index = false; c->n_t = 0;
+}
+
+static void free_source(symmicp_ctx *c)
+{
+    hipFree(c->src0_block); hipFree(c->cur_block); hipFree(c->src_order); hipFree(c->pos); hipFree(c->d2); hipFree(c->best64);
+    c->src0_block = c->cur_block = nullptr; c->src_order = nullptr; c->pos = nullptr; c->d2 = nullptr; c->best64 = nullptr;
+    c->n_loc = c->n_s_total = c->src_off = 0;
+}
+
+void symmicp_destroy(symmicp_ctx *c)
+{
+    if (!c) return;
+    hipSetDevice(c->device);
+    if (c->stream) hipStreamSynchronize(c->stream);
+    if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
+    free_target(c);
+    free_source(c);
+    hipFree(c->partials); hipFree(c->d_sums);
+    if (c->h_sums) hipHostFree(c->h_sums);
+    if (c->ev0) hipEventDestroy(c->ev0);
+    if (c->ev1) hipEventDestroy(c->ev1);
+    if (c->stream) hipStreamDestroy(c->stream);
+    delete c;
+}
+
+const char *symmicp_last_error(const symmicp_ctx *c) { return c ? c->err.c_str() : "null ctx"; }
+
+int symmicp_set_config(symmicp_ctx *c, const symmicp_config *cfg)
+{
+    if (!c) return SYMMICP_ERR_ARG;
+    if (check_cfg(cfg) != SYMMICP_OK) return fail(c, SYMMICP_ERR_ARG, "bad config");
+    // correspondence kind decides device layouts: it can only change before clouds are set
+    if ((c->n_t || c->n_loc) && cfg->corr != c->cfg.corr) return fail(c, SYMMICP_ERR_STATE, "corr cannot change after clouds are set");
+    if ((c->n_t || c->n_loc) && cfg->sort_source != c->cfg.sort_source) return fail(c, SYMMICP_ERR_STATE, "sort_source cannot change after clouds are set");
+    int dev = c->cfg.device;
+    c->cfg = *cfg;
+    c->cfg.device = dev;
+    c->begun = false;
+    return SYMMICP_OK;
+}
+
+// host strided -> planar staging -> device block of 6 arrays
+static int upload_planar(symmicp_ctx *c, const float *xyz, size_t xr, size_t xc, const float *nrm, size_t nr, size_t nc,
+                         size_t n, float **block_out, double centroid[3])
+{
+    std::vector<float> stage(6 * n);
+    double s[3] = {0, 0, 0};
+    for (size_t i = 0; i < n; i++)
+        for (int k = 0; k < 3; k++) {
+            float v = xyz[i * xr + k * xc];
+            stage[(size_t)k * n + i] = v;
+            s[k] += (double)v;
+            stage[(size_t)(3 + k) * n + i] = nrm[i * nr + k * nc];
+        }
+    if (centroid) for (int k = 0; k < 3; k++) centroid[k] = s[k] / (double)n;
+    float *block = nullptr;
+    HIP_TRY(c, hipMalloc((void **)&block, sizeof(float) * 6 * n));
+    hipError_t e = hipMemcpyAsync(block, stage.data(), sizeof(float) * 6 * n, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) { hipFree(block); c->err = std::string("upload: ") + hipGetErrorString(e); return SYMMICP_ERR_HIP; }
+    *block_out = block;
+    return SYMMICP_OK;
+}
+
+static float ord2f(uint32_t o)
+{
+    uint32_t u = (o & 0x80000000u) ? (o & 0x7fffffffu) : ~o;
+    float f;
+    std::memcpy(&f, &u, 4);
+    return f;
+}
+
+// Morton order of a planar cloud: fills order[n] (sorted position -> row) and, optionally, keeps the sorted keys.
+static int morton_order(symmicp_ctx *c, const CloudSoA &cl, uint32_t n, uint32_t **order_out, uint32_t **keys_out,
+                        float origin[3], float *h0_out)
+{
+    uint32_t *bbox = nullptr, *keys = nullptr, *vals = nullptr, *kt = nullptr, *vt = nullptr, *ws = nullptr;
+    const size_t wse = radix_sort_ws_elems(n);
+    HIP_TRY(c, hipMalloc((void **)&bbox, 6 * sizeof(uint32_t)));
+    HIP_TRY(c, hipMalloc((void **)&keys, sizeof(uint32_t) * n));
+    HIP_TRY(c, hipMalloc((void **)&vals, sizeof(uint32_t) * n));
+    HIP_TRY(c, hipMalloc((void **)&kt, sizeof(uint32_t) * n));
+    HIP_TRY(c, hipMalloc((void **)&vt, sizeof(uint32_t) * n));
+    HIP_TRY(c, hipMalloc((void **)&ws, sizeof(uint32_t) * wse));
+    launch_bbox(cl.x, cl.y, cl.z, n, bbox, c->stream);
+    uint32_t hb[6];
+    HIP_TRY(c, hipMemcpyAsync(hb, bbox, sizeof(hb), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    float lo[3], hi[3];
+    for (int k = 0; k < 3; k++) { lo[k] = ord2f(hb[k]); hi[k] = ord2f(hb[3 + k]); }
+    float emax = 0.f;
+    for (int k = 0; k < 3; k++) {
+        if (!std::isfinite(lo[k]) || !std::isfinite(hi[k])) {
+            hipFree(bbox); hipFree(keys); hipFree(vals); hipFree(kt); hipFree(vt); hipFree(ws);
+            return fail(c, SYMMICP_ERR_ARG, "cloud has non-finite coordinates");
+        }
+        emax = std::fmax(emax, hi[k] - lo[k]);
+    }
+    if (!(emax > 0.f)) emax = 1.f;
+    const float h0 = emax * 1.00001f / (float)(1 << kMortonBits);
+    launch_morton(cl.x, cl.y, cl.z, n, lo[0], lo[1], lo[2], 1.0f / h0, keys, vals, c->stream);
+    radix_sort_pairs(keys, vals, kt, vt, n, 3 * kMortonBits, ws, wse, c->stream);
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipGetLastError());
+    hipFree(bbox); hipFree(kt); hipFree(vt); hipFree(ws);
+    *order_out = vals;
+    if (keys_out) *keys_out = keys; else hipFree(keys);
+    for (int k = 0; k < 3; k++) origin[k] = lo[k];
+    *h0_out = h0;
+    return SYMMICP_OK;
+}
+
+// Search index over a planar cloud: Morton sort -> float4 gather -> (optional) dense cell table at the
+// chosen octree level -> implicit 8-ary box tree.  tq/tn must already be allocated (n float4 each).
+static int build_index(symmicp_ctx *c, const CloudSoA &cl, uint32_t n, bool want_grid, float4 *tq, float4 *tn,
+                       float4 **boxes_out, uint2 **cells_out, TargetIndex *ix_out, int32_t *glevel_out, int32_t *nlevels_out)
+{
+    uint32_t *order = nullptr, *keys = nullptr;
+    float origin[3], h0;
+    int st = morton_order(c, cl, n, &order, &keys, origin, &h0);
+    if (st != SYMMICP_OK) return st;
+    launch_gather_f4(cl.x, cl.y, cl.z, cl.nx, cl.ny, cl.nz, order, n, tq, tn, c->stream);
+    TargetIndex ix{};
+    ix.tq = tq; ix.tn = tn; ix.n = n;
+    int glevel = 0;
+    if (want_grid) {
+        uint32_t *hist = nullptr;
+        HIP_TRY(c, hipMalloc((void **)&hist, 16 * sizeof(uint32_t)));
+        launch_level_hist(keys, n, hist, c->stream);
+        uint32_t hh[16];
+        HIP_TRY(c, hipMemcpyAsync(hh, hist, sizeof(hh), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        hipFree(hist);
+        // finest level whose occupied cells still hold >= ppc points on average
+        double ppc = 2.0;
+        if (const char *e = std::getenv("SYMMICP_GRID_PPC")) ppc = std::atof(e);
+        int lcap = 9;                                   // 8^9 cells x 8 B = 1 GiB
+        if (const char *e = std::getenv("SYMMICP_GRID_MAXLEVEL")) lcap = std::atoi(e);
+        if (lcap > kMortonBits) lcap = kMortonBits;
+        glevel = 1;
+        double occ = 1.0;
+        for (int l = 1; l <= lcap; l++) {
+            occ += (double)hh[l];
+            if ((double)n / occ >= ppc) glevel = l;
+        }
+        if (const char *e = std::getenv("SYMMICP_GRID_LEVEL")) glevel = std::atoi(e);   // 0 disables the grid phase
+        if (glevel > lcap) glevel = lcap;
+        if (glevel < 0) glevel = 0;
+    }
+    ix.glevel = glevel;
+    if (glevel > 0) {
+        const size_t ncell = (size_t)1 << (3 * glevel);
+        HIP_TRY(c, hipMalloc((void **)cells_out, sizeof(uint2) * ncell));
+        HIP_TRY(c, hipMemsetAsync(*cells_out, 0, sizeof(uint2) * ncell, c->stream));
+        launch_cell_table(keys, n, glevel, *cells_out, c->stream);
+        ix.cells = *cells_out;
+        ix.gdim = 1 << glevel;
+        ix.ox = origin[0]; ix.oy = origin[1]; ix.oz = origin[2];
+        ix.h = h0 * (float)(1 << (kMortonBits - glevel));
+        ix.inv_h = (1.0f / h0) / (float)(1 << (kMortonBits - glevel));
+    }
+    // tree levels: level 0 = leaves of kLeaf points, each level padded to a multiple of kFan
+    uint32_t cnt[kMaxTreeLevels], pad[kMaxTreeLevels];
+    int nl = 0;
+    uint32_t m = (n + kLeaf - 1) / kLeaf;
+    size_t total = 0;
+    while (true) {
+        cnt[nl] = m;
+        pad[nl] = (m <= (uint32_t)kFan) ? m : ((m + kFan - 1) / kFan) * kFan;
+        ix.level_off[nl] = (uint32_t)total;
+        total += pad[nl];
+        nl++;
+        if (m <= (uint32_t)kFan) break;
+        m = pad[nl - 1] / kFan;
+        if (nl >= kMaxTreeLevels) { hipFree(order); hipFree(keys); return fail(c, SYMMICP_ERR_SIZE, "tree too deep"); }
+    }
+    ix.top = nl - 1;
+    ix.ntop = cnt[nl - 1];
+    HIP_TRY(c, hipMalloc((void **)boxes_out, sizeof(float4) * 2 * total));
+    float4 *boxes = *boxes_out;
+    launch_leaf_boxes(tq, n, boxes + 2 * (size_t)ix.level_off[0], pad[0], c->stream);
+    for (int l = 1; l < nl; l++)
+        launch_node_boxes(boxes + 2 * (size_t)ix.level_off[l - 1], pad[l - 1], boxes + 2 * (size_t)ix.level_off[l], pad[l], c->stream);
+    ix.boxes = boxes;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipGetLastError());
+    hipFree(order); hipFree(keys);
+    *ix_out = ix;
+    if (glevel_out) *glevel_out = glevel;
+    if (nlevels_out) *nlevels_out = nl;
+    return SYMMICP_OK;
+}
+
+int symmicp_set_target(symmicp_ctx *c, const float *xyz, size_t xr, size_t xc, const float *nrm, size_t nr, size_t nc, size_t n)
+{
+    if (!c) return SYMMICP_ERR_ARG;
+    if (!xyz || !nrm) return fail(c, SYMMICP_ERR_ARG, "null target cloud (myicp.cpp:102 assert)");
+    if (n == 0 || n > 0x7fffffffull) return fail(c, SYMMICP_ERR_SIZE, "target size out of range");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const double t0 = now_s();
+    free_target(c);
+    c->begun = false;
+    double cen[3];
+    int st = upload_planar(c, xyz, xr, xc, nrm, nr, nc, n, &c->tgt_block, cen);
+    if (st != SYMMICP_OK) return st;
+    soa_from_block(c->tgt_block, n, c->tgt);
+    c->n_t = (uint32_t)n;
+    for (int k = 0; k < 3; k++) c->pivot[k] = (float)cen[k];
+    c->st.upload_ms += (now_s() - t0) * 1e3;
+    if (c->cfg.corr == SYMMICP_CORR_IDENTITY) return SYMMICP_OK;
+
+    const double t1 = now_s();
+    HIP_TRY(c, hipMalloc((void **)&c->tq, sizeof(float4) * n));
+    HIP_TRY(c, hipMalloc((void **)&c->tn, sizeof(float4) * n));
+    if (c->cfg.corr == SYMMICP_CORR_BRUTE) {
+        launch_iota_f4(c->tgt.x, c->tgt.y, c->tgt.z, c->tgt.nx, c->tgt.ny, c->tgt.nz, c->n_t, c->tq, c->tn, c->stream);
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        c->st.build_ms = (now_s() - t1) * 1e3;
+        return SYMMICP_OK;
+    }
+    st = build_index(c, c->tgt, c->n_t, /*want_grid=*/true, c->tq, c->tn, &c->boxes, &c->cells, &c->ix, &c->st.grid_level, &c->st.tree_levels);
+    if (st != SYMMICP_OK) return st;
+    c->have_index = true;
+    c->st.build_ms = (now_s() - t1) * 1e3;
+    return SYMMICP_OK;
+}
+
+int symmicp_set_source(symmicp_ctx *c, const float *xyz, size_t xr, size_t xc, const float *nrm, size_t nr, size_t nc, size_t n)
+{
+    if (!c) return SYMMICP_ERR_ARG;
+    if (!xyz || !nrm) return fail(c, SYMMICP_ERR_ARG, "null source cloud (myicp.cpp:102 assert)");
+    if (n == 0 || n > 0x7fffffffull) return fail(c, SYMMICP_ERR_SIZE, "source size out of range");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const double t0 = now_s();
+    free_source(c);
+    c->begun = false;
+    float *full = nullptr;
+    int st = upload_planar(c, xyz, xr, xc, nrm, nr, nc, n, &full, nullptr);
+    if (st != SYMMICP_OK) return st;
+    CloudSoA fs;
+    soa_from_block(full, n, fs);
+    c->n_s_total = (uint32_t)n;
+    // contiguous share of the (sorted) source for this rank
+    const uint64_t b0 = (uint64_t)n * (uint64_t)c->rank / (uint64_t)c->nranks;
+    const uint64_t b1 = (uint64_t)n * (uint64_t)(c->rank + 1) / (uint64_t)c->nranks;
+    c->src_off = (uint32_t)b0;
+    c->n_loc = (uint32_t)(b1 - b0);
+    const uint32_t nl = c->n_loc > 0 ? c->n_loc : 1;
+    HIP_TRY(c, hipMalloc((void **)&c->src0_block, sizeof(float) * 6 * nl));
+    HIP_TRY(c, hipMalloc((void **)&c->cur_block, sizeof(float) * 6 * nl));
+    soa_from_block(c->src0_block, nl, c->src0);
+    soa_from_block(c->cur_block, nl, c->cur);
+    const bool sorted = c->cfg.corr != SYMMICP_CORR_IDENTITY && c->cfg.sort_source;
+    if (sorted) {
+        uint32_t *order = nullptr;
+        float origin[3], h0;
+        st = morton_order(c, fs, (uint32_t)n, &order, nullptr, origin, &h0);
+        if (st != SYMMICP_OK) { hipFree(full); return st; }
+        HIP_TRY(c, hipMalloc((void **)&c->src_order, sizeof(uint32_t) * nl));
+        if (c->n_loc) {
+            HIP_TRY(c, hipMemcpyAsync(c->src_order, order + b0, sizeof(uint32_t) * c->n_loc, hipMemcpyDeviceToDevice, c->stream));
+            launch_gather_soa(fs, c->src_order, c->n_loc, c->src0, c->stream);
+        }
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        hipFree(order);
+    } else if (c->n_loc) {
+        const float *from[6] = {fs.x, fs.y, fs.z, fs.nx, fs.ny, fs.nz};
+        float *to[6] = {c->src0.x, c->src0.y, c->src0.z, c->src0.nx, c->src0.ny, c->src0.nz};
+        for (int k = 0; k < 6; k++)
+            HIP_TRY(c, hipMemcpyAsync(to[k], from[k] + b0, sizeof(float) * c->n_loc, hipMemcpyDeviceToDevice, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
+    hipFree(full);
+    HIP_TRY(c, hipMalloc((void **)&c->pos, sizeof(int32_t) * nl));
+    HIP_TRY(c, hipMalloc((void **)&c->d2, sizeof(float) * nl));
+    if (c->cfg.corr == SYMMICP_CORR_BRUTE) HIP_TRY(c, hipMalloc((void **)&c->best64, sizeof(unsigned long long) * nl));
+    HIP_TRY(c, hipGetLastError());
+    c->st.upload_ms += (now_s() - t0) * 1e3;
+    return SYMMICP_OK;
+}
+
+// ---- one pass over the source share ------------------------------------------------------------
+static int run_pass(symmicp_ctx *c, const float Xapply[16], bool from_cur, bool writeback, bool first)
+{
+    PassArgs a{};
+    a.in = from_cur ? c->cur : c->src0;
+    a.out = c->cur;
+    a.n = c->n_loc;
+    a.tgt_offset = c->src_off;
+    for (int k = 0; k < 12; k++) a.X.m[k] = Xapply[k];
+    a.X.nrm_w = (c->cfg.mode == SYMMICP_MODE_QUIRKS) ? 1.0f : 0.0f;   // myicp.cpp:137 quirk
+    const bool paper = c->cfg.mode == SYMMICP_MODE_PAPER;
+    for (int k = 0; k < 3; k++) a.pivot[k] = paper ? c->pivot[k] : 0.0f;
+    a.max_d2 = c->cfg.max_corr_dist > 0.f ? c->cfg.max_corr_dist * c->cfg.max_corr_dist : 0.f;
+    a.writeback = writeback ? 1 : 0;
+    a.best64 = c->best64;
+    a.pos_prev = first ? nullptr : c->pos;
+    a.pos_out = c->pos;
+    a.d2_out = c->d2;
+    a.partials = c->partials;
+    int blocks = (int)((c->n_loc + kPassThreads - 1) / kPassThreads);
+    int cap = 2048;
+    if (const char *e = std::getenv("SYMMICP_PASS_BLOCKS")) cap = std::atoi(e);
+    if (cap > 8192) cap = 8192;
+    if (blocks > cap) blocks = cap;
+    if (blocks < 1) blocks = 1;
+    c->pass_blocks = blocks;
+    if (c->timing) hipEventRecord(c->ev0, c->stream);
+    switch (c->cfg.corr) {
+    case SYMMICP_CORR_IDENTITY:
+        launch_pass_identity(a, c->tgt, blocks, c->stream);
+        break;
+    case SYMMICP_CORR_BRUTE:
+        launch_nn_brute(a.in, c->n_loc, a.X, c->tq, c->n_t, c->best64, c->stream);
+        launch_pass_indexed(a, c->tq, c->tn, blocks, c->stream);
+        break;
+    default:
+        launch_pass_tree(a, c->ix, blocks, c->stream);
+        break;
+    }
+    if (c->timing) hipEventRecord(c->ev1, c->stream);
+    launch_final_reduce(c->partials, blocks, c->d_sums, c->comm ? nullptr : c->h_sums_dev, c->stream);
+    if (c->comm) {
+        int r = g_rccl.AllReduce(c->d_sums, c->d_sums, kNSum, kNcclFloat64, kNcclSum, c->comm, c->stream);
+        if (r != 0) return fail(c, SYMMICP_ERR_COMM, std::string("ncclAllReduce: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?"));
+        HIP_TRY(c, hipMemcpyAsync(c->h_sums, c->d_sums, sizeof(double) * kNSum, hipMemcpyDeviceToHost, c->stream));
+    }
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipGetLastError());
+    std::memcpy(c->last.s, c->h_sums, sizeof(double) * kNSum);
+    if (c->timing) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, c->ev0, c->ev1) == hipSuccess) { c->st.last_pass_ms = ms; c->st.sum_pass_ms += ms; }
+    }
+    c->st.passes++;
+    return SYMMICP_OK;
+}
+
+static int check_ready(symmicp_ctx *c)
+{
+    if (!c->tgt_block || !c->src0_block) return fail(c, SYMMICP_ERR_STATE, "source and target must be set first (myicp.cpp:102)");
+    if (c->cfg.corr == SYMMICP_CORR_IDENTITY && c->n_s_total != c->n_t)
+        return fail(c, SYMMICP_ERR_SIZE, "identity pairing needs N_s == N_t (func.cpp:21)");
+    if (c->cfg.corr == SYMMICP_CORR_TREE && !c->have_index) return fail(c, SYMMICP_ERR_STATE, "target index missing");
+    if (c->cfg.corr != SYMMICP_CORR_IDENTITY && !c->tq) return fail(c, SYMMICP_ERR_STATE, "target was set under a different corr mode");
+    return SYMMICP_OK;
+}
+
+static void fill_iter(symmicp_ctx *c, symmicp_iter_result *out, int status, float rcond, const float *incr)
+{
+    if (!out) return;
+    out->status = status;
+    out->iter = c->iters;
+    out->diff = (float)c->last.s[33];
+    out->rcond = rcond;
+    out->pairs = c->last.s[34];
+    if (incr) std::memcpy(out->increment, incr, sizeof(float) * 16); else identity16(out->increment);
+    out->sums = c->last;
+}
+
+int symmicp_begin(symmicp_ctx *c, const float *guess16, symmicp_iter_result *out)
+{
+    if (!c) return SYMMICP_ERR_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    int st = check_ready(c);
+    if (st != SYMMICP_OK) return st;
+    if (guess16) std::memcpy(c->X, guess16, sizeof(float) * 16); else identity16(c->X);
+    c->iters = 0;
+    const bool incr = resolved_apply(c->cfg) == SYMMICP_APPLY_INCREMENTAL;
+    // incremental: cur <- X * src0 (write-back); cumulative: read src0 through X every pass
+    st = run_pass(c, c->X, /*from_cur=*/false, /*writeback=*/incr, /*first=*/true);
+    if (st != SYMMICP_OK) return st;
+    c->begun = true;
+    fill_iter(c, out, SYMMICP_OK, 1.0f, nullptr);
+    return SYMMICP_OK;
+}
+
+int symmicp_step(symmicp_ctx *c, symmicp_iter_result *out)
+{
+    if (!c) return SYMMICP_ERR_ARG;
+    if (!c->begun) return fail(c, SYMMICP_ERR_STATE, "symmicp_step before symmicp_begin");
+    HIP_TRY(c, hipSetDevice(c->device));
+    float pbar[3], qbar[3], a[3], t[3], rc = 0.f, Xi[16];
+    int st = (c->cfg.mode == SYMMICP_MODE_QUIRKS) ? solve_quirks(c->last, pbar, qbar, a, t, &rc, Xi)
+                                                   : solve_paper(c->last, c->pivot, pbar, qbar, a, t, &rc, Xi);
+    if (st != SYMMICP_OK) {
+        c->err = "degenerate system (rank-deficient normal equations or non-finite transform; func.cpp:70,96)";
+        fill_iter(c, out, st, rc, nullptr);
+        return st;
+    }
+    mat4_mul(Xi, c->X, c->X);                     // myicp.cpp:138
+    const bool incr = resolved_apply(c->cfg) == SYMMICP_APPLY_INCREMENTAL;
+    st = incr ? run_pass(c, Xi, true, true, false) : run_pass(c, c->X, false, false, false);
+    if (st != SYMMICP_OK) return st;
+    c->iters++;
+    fill_iter(c, out, SYMMICP_OK, rc, Xi);
+    return SYMMICP_OK;
+}
+
+int symmicp_align(symmicp_ctx *c, const float *guess16, symmicp_result *out)
+{
+    if (!c || !out) return SYMMICP_ERR_ARG;
+    std::memset(out, 0, sizeof(*out));
+    const double t0 = now_s();
+    symmicp_iter_result it;
+    int st = symmicp_begin(c, guess16, &it);
+    if (st != SYMMICP_OK) { out->status = st; return st; }
+    float diff = it.diff;                                           // myicp.cpp:122
+    out->diff_initial = diff;
+    int iters = 0;
+    while ((c->cfg.fixed_iters || diff > c->cfg.diff_threshold) && iters++ < c->cfg.max_iters) {   // myicp.cpp:123
+        if (c->cfg.verbose) std::printf("iters#%d\ndiff: %g\n", iters, diff);                       // myicp.cpp:125-126
+        if (iters <= 64) out->diffs[iters - 1] = diff;
+        st = symmicp_step(c, &it);
+        if (st != SYMMICP_OK) { iters--; break; }
+        diff = it.diff;                                             // myicp.cpp:141
+    }
+    if (iters > c->cfg.max_iters) iters = c->cfg.max_iters;
+    out->status = st;
+    out->iters = iters;
+    out->diff_final = diff;
+    std::memcpy(out->transform, c->X, sizeof(float) * 16);
+    out->seconds_total = now_s() - t0;
+    if (c->cfg.verbose) {                                           // myicp.cpp:146-149
+        const float *X = c->X;
+        std::printf("Result transform:\n");
+        for (int r = 0; r < 4; r++) std::printf("%g %g %g %g\n", X[4 * r], X[4 * r + 1], X[4 * r + 2], X[4 * r + 3]);
+        std::printf("  rotation:\n");
+        for (int r = 0; r < 3; r++) std::printf("%g %g %g\n", X[4 * r], X[4 * r + 1], X[4 * r + 2]);
+        std::printf("  translation:\n%g\n%g\n%g\n", X[3], X[7], X[11]);
+    }
+    return st;
+}
+
+int symmicp_get_transform(const symmicp_ctx *c, float out16[16])
+{
+    if (!c || !out16) return SYMMICP_ERR_ARG;
+    std::memcpy(out16, c->X, sizeof(float) * 16);
+    return SYMMICP_OK;
+}
+
+int symmicp_get_pivot(const symmicp_ctx *c, float out3[3])
+{
+    if (!c || !out3) return SYMMICP_ERR_ARG;
+    const bool paper = c->cfg.mode == SYMMICP_MODE_PAPER;
+    for (int k = 0; k < 3; k++) out3[k] = paper ? c->pivot[k] : 0.f;
+    return SYMMICP_OK;
+}
+
+size_t symmicp_local_source_count(const symmicp_ctx *c) { return c ? c->n_loc : 0; }
+size_t symmicp_local_source_offset(const symmicp_ctx *c) { return c ? c->src_off : 0; }
+
+// rows are reported relative to this rank's share; with a sorted source the share is a set of
+// caller rows (not a contiguous range), so indices are written at [row] of a full-size array.
+int symmicp_get_correspondences(symmicp_ctx *c, int32_t *idx, float *d2, size_t cap)
+{
+    if (!c) return SYMMICP_ERR_ARG;
+    if (!c->begun) return fail(c, SYMMICP_ERR_STATE, "no pass has run yet");
+    const size_t need = c->src_order ? c->n_s_total : c->n_loc;
+    if (cap < need) return fail(c, SYMMICP_ERR_SIZE, "output too small");
+    HIP_TRY(c, hipSetDevice(c->device));
+    int32_t *d_idx = nullptr;
+    float *d_d2 = nullptr;
+    HIP_TRY(c, hipMalloc((void **)&d_idx, sizeof(int32_t) * need));
+    HIP_TRY(c, hipMalloc((void **)&d_d2, sizeof(float) * need));
+    HIP_TRY(c, hipMemsetAsync(d_idx, 0xFF, sizeof(int32_t) * need, c->stream));
+    HIP_TRY(c, hipMemsetAsync(d_d2, 0, sizeof(float) * need, c->stream));
+    const int mode = c->cfg.corr == SYMMICP_CORR_IDENTITY ? 0 : (c->cfg.corr == SYMMICP_CORR_BRUTE ? 1 : 2);
+    launch_corr_out(c->pos, c->best64, c->d2, c->tq, c->src_order, c->n_loc, mode, c->src_off, d_idx, d_d2, c->stream);
+    if (idx) HIP_TRY(c, hipMemcpyAsync(idx, d_idx, sizeof(int32_t) * need, hipMemcpyDeviceToHost, c->stream));
+    if (d2) HIP_TRY(c, hipMemcpyAsync(d2, d_d2, sizeof(float) * need, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    hipFree(d_idx); hipFree(d_d2);
+    return SYMMICP_OK;
+}
+
+int symmicp_get_source(symmicp_ctx *c, float *xyz, float *nrm, size_t cap)
+{
+    if (!c) return SYMMICP_ERR_ARG;
+    if (!c->begun) return fail(c, SYMMICP_ERR_STATE, "no pass has run yet");
+    if (resolved_apply(c->cfg) != SYMMICP_APPLY_INCREMENTAL)
+        return fail(c, SYMMICP_ERR_STATE, "the transformed source is only materialised with SYMMICP_APPLY_INCREMENTAL");
+    const size_t need = c->src_order ? c->n_s_total : c->n_loc;
+    if (cap < need) return fail(c, SYMMICP_ERR_SIZE, "output too small");
+    HIP_TRY(c, hipSetDevice(c->device));
+    float *dx = nullptr, *dn = nullptr;
+    HIP_TRY(c, hipMalloc((void **)&dx, sizeof(float) * 3 * need));
+    HIP_TRY(c, hipMalloc((void **)&dn, sizeof(float) * 3 * need));
+    HIP_TRY(c, hipMemsetAsync(dx, 0, sizeof(float) * 3 * need, c->stream));
+    HIP_TRY(c, hipMemsetAsync(dn, 0, sizeof(float) * 3 * need, c->stream));
+    launch_unpermute(c->cur, c->src_order, c->n_loc, dx, dn, c->stream);
+    if (xyz) HIP_TRY(c, hipMemcpyAsync(xyz, dx, sizeof(float) * 3 * need, hipMemcpyDeviceToHost, c->stream));
+    if (nrm) HIP_TRY(c, hipMemcpyAsync(nrm, dn, sizeof(float) * 3 * need, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    hipFree(dx); hipFree(dn);
+    return SYMMICP_OK;
+}
+
+int symmicp_solve(int mode, const symmicp_sums *sums, const float pivot[3], float pbar[3], float qbar[3], float a[3],
+                  float t[3], float *rcond, float out16[16])
+{
+    if (!sums || !pbar || !qbar || !a || !t || !out16) return SYMMICP_ERR_ARG;
+    if (mode == SYMMICP_MODE_QUIRKS) return solve_quirks(*sums, pbar, qbar, a, t, rcond, out16);
+    if (mode == SYMMICP_MODE_PAPER) return solve_paper(*sums, pivot, pbar, qbar, a, t, rcond, out16);
+    return SYMMICP_ERR_ARG;
+}
+
+// ---- normals pre-step (MyICP::estimateNormals, myicp.cpp:152-172) --------------------------------
+int symmicp_estimate_normals(int device, const float *xyz, size_t row_stride, size_t col_stride, size_t n, int k,
+                             const float viewpoint[3], float *nrm_out, float *curv_out)
+{
+    if (!xyz || !nrm_out || n == 0 || n > 0x7fffffffull) return SYMMICP_ERR_ARG;
+    if (k < 3 || k > 16 || (size_t)k > n) return SYMMICP_ERR_ARG;
+    symmicp_config cfg;
+    symmicp_config_default(&cfg);
+    cfg.device = device;
+    symmicp_ctx *c = nullptr;
+    int st = symmicp_create(&cfg, &c);
+    if (st != SYMMICP_OK) return st;
+    float *block = nullptr, *d_nrm = nullptr, *d_curv = nullptr;
+    float4 *tq = nullptr, *tn = nullptr, *boxes = nullptr;
+    uint2 *cells = nullptr;
+    auto cleanup = [&]() {
+        hipFree(block); hipFree(d_nrm); hipFree(d_curv); hipFree(tq); hipFree(tn); hipFree(boxes); hipFree(cells);
+        symmicp_destroy(c);
+    };
+    // the cloud has no normals yet: stage xyz twice (the normal slots are ignored)
+    st = upload_planar(c, xyz, row_stride, col_stride, xyz, row_stride, col_stride, n, &block, nullptr);
+    if (st != SYMMICP_OK) { cleanup(); return st; }
+    CloudSoA cl;
+    soa_from_block(block, n, cl);
+    TargetIndex ix{};
+    bool ok = hipMalloc((void **)&tq, sizeof(float4) * n) == hipSuccess && hipMalloc((void **)&tn, sizeof(float4) * n) == hipSuccess &&
+              hipMalloc((void **)&d_nrm, sizeof(float) * 3 * n) == hipSuccess && hipMalloc((void **)&d_curv, sizeof(float) * n) == hipSuccess;
+    if (!ok) { cleanup(); return SYMMICP_ERR_HIP; }
+    st = build_index(c, cl, (uint32_t)n, /*want_grid=*/false, tq, tn, &boxes, &cells, &ix, nullptr, nullptr);
+    if (st != SYMMICP_OK) { cleanup(); return st; }
+    const float vp0[3] = {0.f, 0.f, 0.f};
+    launch_normals_knn(ix, k, viewpoint ? viewpoint : vp0, d_nrm, d_curv, c->stream);
+    hipError_t e = hipMemcpyAsync(nrm_out, d_nrm, sizeof(float) * 3 * n, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess && curv_out) e = hipMemcpyAsync(curv_out, d_curv, sizeof(float) * n, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess) e = hipGetLastError();
+    cleanup();
+    return e == hipSuccess ? SYMMICP_OK : SYMMICP_ERR_HIP;
+}
+
+// ---- multi-GPU ---------------------------------------------------------------------------------
+int symmicp_comm_get_unique_id(void *out128)
+{
+    if (!out128) return SYMMICP_ERR_ARG;
+    if (!g_rccl.load()) return SYMMICP_ERR_COMM;
+    rcclUniqueId id;
+    if (g_rccl.GetUniqueId(&id) != 0) return SYMMICP_ERR_COMM;
+    std::memcpy(out128, &id, SYMMICP_UNIQUE_ID_BYTES);
+    return SYMMICP_OK;
+}
+
+int symmicp_comm_init_rank(symmicp_ctx *c, int nranks, int rank, const void *uid)
+{
+    if (!c) return SYMMICP_ERR_ARG;
+    if (nranks < 1 || rank < 0 || rank >= nranks) return fail(c, SYMMICP_ERR_ARG, "bad rank/nranks");
+    if (c->src0_block) return fail(c, SYMMICP_ERR_STATE, "attach the communicator before symmicp_set_source");
+    if (nranks == 1) { c->nranks = 1; c->rank = 0; return SYMMICP_OK; }
+    if (!uid) return fail(c, SYMMICP_ERR_ARG, "null unique id");
+    if (!g_rccl.load()) return fail(c, SYMMICP_ERR_COMM, g_rccl.err);
+    HIP_TRY(c, hipSetDevice(c->device));
+    rcclUniqueId id;
+    std::memcpy(&id, uid, SYMMICP_UNIQUE_ID_BYTES);
+    int r = g_rccl.CommInitRank(&c->comm, nranks, id, rank);
+    if (r != 0) return fail(c, SYMMICP_ERR_COMM, std::string("ncclCommInitRank: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?"));
+    c->nranks = nranks;
+    c->rank = rank;
+    return SYMMICP_OK;
+}
+
+// ---- stats -------------------------------------------------------------------------------------
+int symmicp_enable_timing(symmicp_ctx *c, int on)
+{
+    if (!c) return SYMMICP_ERR_ARG;
+    c->timing = on != 0;
+    return SYMMICP_OK;
+}
+
+int symmicp_reset_stats(symmicp_ctx *c)
+{
+    if (!c) return SYMMICP_ERR_ARG;
+    c->st.last_pass_ms = c->st.sum_pass_ms = 0.0;
+    c->st.passes = 0;
+    return SYMMICP_OK;
+}
+
+int symmicp_get_stats(symmicp_ctx *c, symmicp_stats *out)
+{
+    if (!c || !out) return SYMMICP_ERR_ARG;
+    c->st.pass_blocks = c->pass_blocks;
+    const bool incr = resolved_apply(c->cfg) == SYMMICP_APPLY_INCREMENTAL;
+    int64_t b = 0;
+    if (c->cfg.corr == SYMMICP_CORR_IDENTITY) b = (int64_t)c->n_loc * 48;
+    else b = (int64_t)c->n_loc * (48 + 4 + 4) + (int64_t)c->n_t * 12;
+    if (incr) b += (int64_t)c->n_loc * 24;
+    c->st.bytes_algorithmic_per_pass = b;
+    *out = c->st;
+    return SYMMICP_OK;
+}
+
+}  // extern "C"

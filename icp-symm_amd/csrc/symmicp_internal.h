@@ -1,0 +1,104 @@
+// symmicp_internal.h -- shared between the HIP kernels and the host engine.
+// gfx950 (MI355X, CDNA4) only: wave = 64 lanes, 256 CUs in 8 XCDs, 160 KB LDS/CU.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include "symmicp.h"
+
+namespace symmicp {
+
+constexpr int kNSum = SYMMICP_NSUM;   // 40 doubles per reduction record
+constexpr int kNAcc = 37;             // live accumulators (rest of the record is 0)
+constexpr int kLeaf = 8;              // target points per leaf (8 x 16 B = one 128-B line)
+constexpr int kFan = 8;               // children per tree node
+constexpr int kMaxTreeLevels = 12;
+constexpr int kMortonBits = 10;       // per axis -> 30-bit keys
+constexpr int kPassThreads = 256;
+constexpr int kBruteTile = 1024;      // target points staged in LDS per tile (16 KB)
+constexpr int kBruteQ = 4;            // queries per thread in the brute-force kernel
+
+// 3x4 affine passed by value in kernel arguments (row-major), plus the weight
+// the translation column gets when it is applied to normals
+// (1 = reference quirk myicp.cpp:137, 0 = rotate only).
+struct Affine {
+    float m[12];
+    float nrm_w;
+};
+
+// planar (structure-of-arrays) cloud: the layout of the reference's column-major
+// Eigen::MatrixXf N x 3 blocks (func.cpp:5-15).
+struct CloudSoA {
+    float *x, *y, *z, *nx, *ny, *nz;
+};
+
+// Search index over the target: Morton-sorted points, dense cell table at one
+// octree level (the "grid"), and an implicit 8-ary tree of tight boxes over
+// runs of the sorted order (the "linear BVH").
+struct TargetIndex {
+    const float4 *tq;        // sorted: xyz + original row (int bits) in w
+    const float4 *tn;        // sorted: normal xyz, w = 0
+    uint32_t n;
+    // tree: 2 float4 per node (lo, hi); level l starts at node level_off[l]
+    const float4 *boxes;
+    uint32_t level_off[kMaxTreeLevels];
+    int32_t top;             // index of the top level
+    uint32_t ntop;           // nodes in the top level (<= kFan)
+    // grid
+    const uint2 *cells;      // [8^glevel] (first, last+1) of each Morton cell, 0/0 when empty
+    int32_t glevel;          // 0 = no grid
+    int32_t gdim;            // 1 << glevel
+    float ox, oy, oz;        // grid origin (target bbox min)
+    float h, inv_h;          // cell edge at glevel
+};
+
+struct PassArgs {
+    // source share (planar).  `in` is read; if writeback, `out` receives the transformed points/normals
+    CloudSoA in, out;
+    uint32_t n;              // points in this share
+    uint32_t tgt_offset;     // identity pairing: target row = tgt_offset + i
+    Affine X;                // transform applied to `in` on the fly
+    float pivot[3];          // subtracted from p and q before forming rows (0 in QUIRKS)
+    float max_d2;            // <= 0: keep all pairs
+    int32_t writeback;
+    // correspondences
+    const unsigned long long *best64;   // BRUTE: (d2 bits << 32 | target row), ~0 = none
+    int32_t *pos_prev;                  // TREE: sorted position found by the previous pass (-1 = none); updated
+    float *d2_out;                      // optional per-point squared distance (may be null)
+    int32_t *pos_out;                   // sorted position / target row chosen this pass (may alias pos_prev)
+    double *partials;                   // [blocks][kNSum]
+};
+
+// ---- kernel launchers (kernels.hip) ---------------------------------------
+void launch_pass_identity(const PassArgs &a, CloudSoA tgt, int blocks, hipStream_t s);
+void launch_pass_indexed(const PassArgs &a, const float4 *tq, const float4 *tn, int blocks, hipStream_t s);
+void launch_pass_tree(const PassArgs &a, const TargetIndex &ix, int blocks, hipStream_t s);
+void launch_final_reduce(const double *partials, int blocks, double *out_dev, double *out_host_mapped, hipStream_t s);
+void launch_nn_brute(const CloudSoA &src, uint32_t n_s, const Affine &X, const float4 *tq, uint32_t n_t,
+                     unsigned long long *best64, hipStream_t s);
+
+// index build
+void launch_bbox(const float *x, const float *y, const float *z, uint32_t n, uint32_t *bbox_ord6, hipStream_t s);
+void launch_morton(const float *x, const float *y, const float *z, uint32_t n, float ox, float oy, float oz,
+                   float inv_h0, uint32_t *keys, uint32_t *vals, hipStream_t s);
+// sorts (keys, vals) ascending, stable; tmp arrays same size; result lands back in keys/vals
+void radix_sort_pairs(uint32_t *keys, uint32_t *vals, uint32_t *keys_tmp, uint32_t *vals_tmp, uint32_t n,
+                      int key_bits, uint32_t *hist_ws, size_t hist_ws_elems, hipStream_t s);
+size_t radix_sort_ws_elems(uint32_t n);
+void launch_gather_f4(const float *x, const float *y, const float *z, const float *nx, const float *ny, const float *nz,
+                      const uint32_t *order, uint32_t n, float4 *tq, float4 *tn, hipStream_t s);
+void launch_gather_soa(const CloudSoA &src, const uint32_t *order, uint32_t n, CloudSoA dst, hipStream_t s);
+void launch_level_hist(const uint32_t *keys, uint32_t n, uint32_t *hist16, hipStream_t s);
+void launch_cell_table(const uint32_t *keys, uint32_t n, int glevel, uint2 *cells, hipStream_t s);
+void launch_leaf_boxes(const float4 *tq, uint32_t n, float4 *boxes, uint32_t nleaf_padded, hipStream_t s);
+void launch_node_boxes(const float4 *child, uint32_t nchild_padded, float4 *parent, uint32_t nparent_padded, hipStream_t s);
+void launch_iota_f4(const float *x, const float *y, const float *z, const float *nx, const float *ny, const float *nz,
+                    uint32_t n, float4 *tq, float4 *tn, hipStream_t s);
+void launch_unpermute(const CloudSoA &cur, const uint32_t *order, uint32_t n, float *xyz_aos, float *nrm_aos, hipStream_t s);
+void launch_corr_out(const int32_t *pos, const unsigned long long *best64, const float *d2, const float4 *tq,
+                     const uint32_t *src_order, uint32_t n, int mode, uint32_t tgt_offset, int32_t *idx_out, float *d2_out,
+                     hipStream_t s);
+
+void launch_normals_knn(const TargetIndex &ix, int k, const float vp[3], float *nrm_out, float *curv_out, hipStream_t s);
+
+}  // namespace symmicp

@@ -1,0 +1,140 @@
+"""Synthetic cloud pairs for the BASELINE.json configs.
+
+Counter-based (splitmix64) so every box, rank and language regenerates the same
+bits without shipping data.  numpy only; inputs for both the HIP path and the
+CPU oracle.
+
+  c3_uniform(n)  C3: i.i.d. uniform cube, random unit normals, 5 deg + small t, target row-shuffled
+  c4_surface(n)  C4: height-field surface with analytic normals, target = a DIFFERENT sampling of
+                     the same surface moved by 3 deg + small t (no exact twins)
+  c5_scan(n)     C5: scan-like rings ray-cast onto the C4 surface + a ground plane, range noise
+  perturbed(xyz, nrm, deg, axis, t)  C2 substitute: a cloud against its own rigid perturbation
+"""
+import numpy as np
+
+_M64 = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+
+def splitmix64(seed, n, stream=0):
+    """n uint64 values: splitmix64 applied to counters seed + (stream << 40) + i."""
+    with np.errstate(over="ignore"):
+        z = (np.arange(1, n + 1, dtype=np.uint64) + np.uint64(seed) + (np.uint64(stream) << np.uint64(40)))
+        z = z * np.uint64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    return z
+
+
+def uniform01(seed, n, stream=0):
+    """float64 in [0,1) with 53 random bits"""
+    return (splitmix64(seed, n, stream) >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)
+
+
+def rotation(deg, axis):
+    a = np.asarray(axis, np.float64)
+    a = a / np.linalg.norm(a)
+    th = np.deg2rad(deg)
+    K = np.array([[0, -a[2], a[1]], [a[2], 0, -a[0]], [-a[1], a[0], 0]])
+    return np.eye(3) + np.sin(th) * K + (1 - np.cos(th)) * (K @ K)
+
+
+def rigid4(R, t):
+    X = np.eye(4)
+    X[:3, :3] = R
+    X[:3, 3] = t
+    return X
+
+
+def _unit_sphere(seed, n, stream):
+    z = 2.0 * uniform01(seed, n, stream) - 1.0
+    ph = 2.0 * np.pi * uniform01(seed, n, stream + 1)
+    r = np.sqrt(np.maximum(0.0, 1.0 - z * z))
+    return np.stack([r * np.cos(ph), r * np.sin(ph), z], 1)
+
+
+def shuffle_perm(seed, n):
+    return np.argsort(splitmix64(seed, n, 7), kind="stable")
+
+
+def c3_uniform(n=100_000, seed=0xC3):
+    src = np.stack([uniform01(seed, n, 0), uniform01(seed, n, 1), uniform01(seed, n, 2)], 1)
+    nrm = _unit_sphere(seed, n, 3)
+    R = rotation(5.0, (1, 2, 3))
+    t = np.array([0.01, -0.02, 0.015])
+    perm = shuffle_perm(seed + 1, n)
+    tgt = (src @ R.T + t)[perm]
+    tn = (nrm @ R.T)[perm]
+    return dict(src=src.astype(np.float32), src_n=nrm.astype(np.float32), tgt=tgt.astype(np.float32),
+                tgt_n=tn.astype(np.float32), truth=rigid4(R, t), perm=perm)
+
+
+def _surface(u, v):
+    z = 0.1 * np.sin(4 * np.pi * u) * np.cos(6 * np.pi * v) + 0.05 * np.sin(10 * np.pi * u + 1.0)
+    dzu = 0.4 * np.pi * np.cos(4 * np.pi * u) * np.cos(6 * np.pi * v) + 0.5 * np.pi * np.cos(10 * np.pi * u + 1.0)
+    dzv = -0.6 * np.pi * np.sin(4 * np.pi * u) * np.sin(6 * np.pi * v)
+    nrm = np.stack([-dzu, -dzv, np.ones_like(u)], 1)
+    nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    return np.stack([u, v, z], 1), nrm
+
+
+def c4_surface(n=1_000_000, seed=0xC4):
+    ps, ns = _surface(uniform01(seed, n, 0), uniform01(seed, n, 1))
+    pt, nt = _surface(uniform01(seed + 1, n, 0), uniform01(seed + 1, n, 1))
+    R = rotation(3.0, (2, -1, 4))
+    t = np.array([0.004, 0.003, -0.002])
+    tgt = pt @ R.T + t
+    tn = nt @ R.T
+    return dict(src=ps.astype(np.float32), src_n=ns.astype(np.float32), tgt=tgt.astype(np.float32),
+                tgt_n=tn.astype(np.float32), truth=rigid4(R, t))
+
+
+def c5_scan(n=8_000_000, seed=0xC5, rings=64):
+    """Scan-like: `rings` elevation rings x (n/rings) azimuth samples from a sensor above the C4 surface;
+    rays hit the height field (solved by fixed-point iteration on the ray parameter) or a ground plane
+    z = -0.2; range noise sigma = 1e-3.  Density falls off with range as in a real sweep."""
+    per = n // rings
+    n = per * rings
+    ring = np.repeat(np.arange(rings), per)
+    az = 2 * np.pi * (np.tile(np.arange(per), rings) + uniform01(seed, n, 0)) / per
+    elev = np.deg2rad(-35.0 + 30.0 * (ring + uniform01(seed, n, 1)) / rings)      # -35 .. -5 deg
+    origin = np.array([0.5, 0.5, 0.45])
+    d = np.stack([np.cos(elev) * np.cos(az), np.cos(elev) * np.sin(az), np.sin(elev)], 1)
+    # ground plane hit
+    s = (-0.2 - origin[2]) / d[:, 2]
+    for _ in range(12):   # refine against the height field where the ray lands inside [0,1)^2
+        p = origin + d * s[:, None]
+        inside = (p[:, 0] >= 0) & (p[:, 0] < 1) & (p[:, 1] >= 0) & (p[:, 1] < 1)
+        zs = _surface(np.clip(p[:, 0], 0, 1), np.clip(p[:, 1], 0, 1))[0][:, 2]
+        s_new = (zs - origin[2]) / d[:, 2]
+        s = np.where(inside, 0.5 * s + 0.5 * s_new, s)
+    noise = 1e-3 * np.sqrt(-2 * np.log(1 - uniform01(seed, n, 2))) * np.cos(2 * np.pi * uniform01(seed, n, 3))
+    p = origin + d * (s + noise)[:, None]
+    inside = (p[:, 0] >= 0) & (p[:, 0] < 1) & (p[:, 1] >= 0) & (p[:, 1] < 1)
+    nrm = np.where(inside[:, None], _surface(np.clip(p[:, 0], 0, 1), np.clip(p[:, 1], 0, 1))[1], np.array([0.0, 0.0, 1.0]))
+    R = rotation(2.0, (1, 1, 5))
+    t = np.array([0.003, -0.002, 0.001])
+    # target: the same sweep half an azimuth step later (different sample points), moved rigidly
+    az2 = az + np.pi / per
+    d2 = np.stack([np.cos(elev) * np.cos(az2), np.cos(elev) * np.sin(az2), np.sin(elev)], 1)
+    s2 = (-0.2 - origin[2]) / d2[:, 2]
+    for _ in range(12):
+        p2 = origin + d2 * s2[:, None]
+        in2 = (p2[:, 0] >= 0) & (p2[:, 0] < 1) & (p2[:, 1] >= 0) & (p2[:, 1] < 1)
+        zs = _surface(np.clip(p2[:, 0], 0, 1), np.clip(p2[:, 1], 0, 1))[0][:, 2]
+        s2 = np.where(in2, 0.5 * s2 + 0.5 * (zs - origin[2]) / d2[:, 2], s2)
+    noise2 = 1e-3 * np.sqrt(-2 * np.log(1 - uniform01(seed + 1, n, 2))) * np.cos(2 * np.pi * uniform01(seed + 1, n, 3))
+    p2 = origin + d2 * (s2 + noise2)[:, None]
+    in2 = (p2[:, 0] >= 0) & (p2[:, 0] < 1) & (p2[:, 1] >= 0) & (p2[:, 1] < 1)
+    n2 = np.where(in2[:, None], _surface(np.clip(p2[:, 0], 0, 1), np.clip(p2[:, 1], 0, 1))[1], np.array([0.0, 0.0, 1.0]))
+    return dict(src=p.astype(np.float32), src_n=nrm.astype(np.float32), tgt=(p2 @ R.T + t).astype(np.float32),
+                tgt_n=(n2 @ R.T).astype(np.float32), truth=rigid4(R, t))
+
+
+def perturbed(xyz, nrm, deg=15.0, axis=(0.3, 0.5, 0.8), t=(1.0, -2.0, 0.5)):
+    """C2 substitute: target = R(deg, axis) * cloud + t, same row order."""
+    R = rotation(deg, axis)
+    tt = np.asarray(t, np.float64)
+    return dict(src=np.asarray(xyz, np.float32), src_n=np.asarray(nrm, np.float32),
+                tgt=(np.asarray(xyz, np.float64) @ R.T + tt).astype(np.float32),
+                tgt_n=(np.asarray(nrm, np.float64) @ R.T).astype(np.float32), truth=rigid4(R, tt))

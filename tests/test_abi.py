@@ -1,0 +1,103 @@
+"""CPU tests of the drop-in boundary: the C-ABI library builds for gfx950, loads, and exports every
+symbol include/symmicp.h declares.  No compute calls (there is no GPU here)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, GOLDEN
+
+
+@pytest.fixture(scope="module")
+def sym():
+    import symmicp
+    if not os.path.exists(symmicp.LIB_PATH):
+        import __graft_entry__ as ge
+        ge.build()
+    return symmicp
+
+
+def test_header_symbols_are_exported(sym):
+    hdr = open(os.path.join(ROOT, "include", "symmicp.h")).read()
+    declared = sorted(set(re.findall(r"\b(symmicp_[a-z0-9_]+)\s*\(", hdr)))
+    assert len(declared) >= 25
+    L = ctypes.CDLL(sym.LIB_PATH)
+    missing = [n for n in declared if not hasattr(L, n)]
+    assert not missing, missing
+    assert sorted(sym.EXPORTS) == declared
+
+
+def test_struct_sizes_match_header(sym):
+    cfg = sym.default_config()
+    assert cfg.struct_size == ctypes.sizeof(sym.Config) == 64
+    assert cfg.max_iters == 10 and cfg.diff_threshold == 1.0          # myicp.cpp:6
+    assert cfg.mode == sym.MODE_QUIRKS and cfg.corr == sym.CORR_IDENTITY
+    assert ctypes.sizeof(sym.Sums) == 8 * sym.NSUM
+    assert sym.lib().symmicp_version() >= 100
+
+
+def test_create_fails_loudly_without_gpu(sym):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(sym.SymmIcpError) as e:
+        sym.Engine()
+    assert e.value.status == sym.ERR_HIP     # no CPU fallback
+
+
+def test_code_object_is_gfx950_only(sym):
+    blob = open(sym.LIB_PATH, "rb").read()
+    assert b"gfx950" in blob
+    for other in (b"gfx90a", b"gfx942", b"sm_"):
+        assert other not in blob
+
+
+def test_host_solve_matches_oracle(sym, oracle, cat):
+    """symmicp_solve is pure host code (func.cpp:76-102 after the reduction) -> testable on CPU."""
+    S = oracle.reduce40(cat["src"], cat["src_n"], cat["tgt"], cat["tgt_n"])
+    st, pb, qb, a, t, rc, X = sym.solve(sym.MODE_QUIRKS, S)
+    st2, pb2, qb2, a2, t2, rc2 = oracle.solve_quirks_gram(S)
+    assert st == st2 == 0
+    np.testing.assert_allclose(a, a2, rtol=2e-6)
+    np.testing.assert_allclose(t, t2, rtol=2e-6, atol=1e-7)
+    np.testing.assert_allclose(X, oracle.compose(pb2, qb2, a2, t2, paper=False), rtol=1e-5, atol=1e-5)
+    pivot = cat["tgt"].astype(np.float64).mean(0).astype(np.float32)
+    S = oracle.reduce40(cat["src"], cat["src_n"], cat["tgt"], cat["tgt_n"], pivot=pivot)
+    st, pb, qb, a, t, rc, X = sym.solve(sym.MODE_PAPER, S, pivot)
+    st2, pb2, qb2, a2, t2, rc2 = oracle.solve_paper(S, pivot)
+    assert st == st2 == 0
+    np.testing.assert_allclose(a, a2, rtol=2e-6, atol=1e-8)
+    np.testing.assert_allclose(X, oracle.compose(pb2, qb2, a2, t2, paper=True), rtol=1e-5, atol=1e-5)
+    c, s = np.cos(np.pi / 4), np.sin(np.pi / 4)
+    T = np.array([[c, -s, 0, 2.5], [s, c, 0, 0], [0, 0, 1, 0], [0, 0, 0, 1]])
+    assert np.abs(X - T).max() < 1e-4     # PAPER + identity pairing: exact in one step
+
+
+def test_host_solve_flags_degenerate(sym):
+    S = np.zeros(sym.NSUM)
+    S[34] = 100.0
+    for mode in (sym.MODE_QUIRKS, sym.MODE_PAPER):
+        st = sym.solve(mode, S)[0]
+        assert st == sym.ERR_DEGENERATE
+
+
+def test_pcd_io_roundtrip(sym, oracle, tmp_path):
+    xyz, nrm = sym.pcd_read(os.path.join(GOLDEN, "cat.pcd"))
+    xyz_o, _ = oracle.pcd_read(os.path.join(GOLDEN, "cat.pcd"))
+    assert nrm is None and np.array_equal(xyz, xyz_o)
+    xyz2, nrm2 = sym.pcd_read(os.path.join(GOLDEN, "cat_out.pcd"))
+    xyz2_o, _ = oracle.pcd_read(os.path.join(GOLDEN, "cat_out.pcd"))
+    assert nrm2 is not None and np.array_equal(xyz2, xyz2_o)
+    rng = np.random.default_rng(0)
+    n = rng.standard_normal((100, 3)).astype(np.float32)
+    for binary in (False, True):
+        p = str(tmp_path / ("t%d.pcd" % binary))
+        sym.pcd_write(p, xyz[:100], n, binary=binary)
+        a, b = sym.pcd_read(p)
+        assert np.array_equal(a, xyz[:100]) and np.array_equal(b, n)
+        a2, b2 = oracle.pcd_read(p)
+        assert np.array_equal(a2, xyz[:100]) and np.array_equal(b2, n)
+    with pytest.raises(sym.SymmIcpError):
+        sym.pcd_read(str(tmp_path / "missing.pcd"))
