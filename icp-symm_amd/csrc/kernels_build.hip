@@ -28,7 +28,11 @@ __global__ __launch_bounds__(256) void k_bbox(const float *__restrict__ x, const
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         float v[3] = {x[i], y[i], z[i]};
 #pragma unroll
-        for (int k = 0; k < 3; k++) { lo[k] = fminf(lo[k], v[k]); hi[k] = fmaxf(hi[k], v[k]); }
+        for (int k = 0; k < 3; k++) {
+            // fminf/fmaxf drop NaN: poison the box instead so the host sees a non-finite extent
+            if (!(fabsf(v[k]) < inf)) { lo[k] = -inf; hi[k] = inf; }
+            lo[k] = fminf(lo[k], v[k]); hi[k] = fmaxf(hi[k], v[k]);
+        }
     }
 #pragma unroll
     for (int k = 0; k < 3; k++)
