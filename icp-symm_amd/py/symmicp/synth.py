@@ -15,15 +15,21 @@ import numpy as np
 _M64 = np.uint64(0xFFFFFFFFFFFFFFFF)
 
 
-def splitmix64(seed, n, stream=0):
-    """n uint64 values: splitmix64 applied to counters seed + (stream << 40) + i."""
+def _mix64(z):
     with np.errstate(over="ignore"):
-        z = (np.arange(1, n + 1, dtype=np.uint64) + np.uint64(seed) + (np.uint64(stream) << np.uint64(40)))
-        z = z * np.uint64(0x9E3779B97F4A7C15)
         z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
         z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
         z = z ^ (z >> np.uint64(31))
     return z
+
+
+def splitmix64(seed, n, stream=0):
+    """n uint64 values.  (seed, stream) is hashed into a base first, so neighbouring seeds or streams
+    give unrelated sequences; value i = mix64(base + (i+1) * golden)."""
+    with np.errstate(over="ignore"):
+        base = _mix64(np.array([np.uint64(seed) * np.uint64(0x9E3779B97F4A7C15) + np.uint64(stream) * np.uint64(0xD1B54A32D192ED03) + np.uint64(0x2545F4914F6CDD1D)], np.uint64))[0]
+        z = base + np.arange(1, n + 1, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15)
+    return _mix64(z)
 
 
 def uniform01(seed, n, stream=0):
@@ -89,44 +95,71 @@ def c4_surface(n=1_000_000, seed=0xC4):
                 tgt_n=tn.astype(np.float32), truth=rigid4(R, t))
 
 
+def _height(x, y):
+    """C4 height field extended periodically, clipped from below by a ground plane z = -0.12"""
+    z = 0.1 * np.sin(4 * np.pi * x) * np.cos(6 * np.pi * y) + 0.05 * np.sin(10 * np.pi * x + 1.0)
+    return np.maximum(z, -0.12)
+
+
+def _raycast(origin, d):
+    """first hit of rays origin + s d (d.z < 0) with the clipped height field: coarse march + bisection"""
+    s_max = (-0.16 - origin[2]) / d[:, 2]                 # below the ground plane: g(s_max) < 0
+    lo = np.zeros(len(d))
+    hi = s_max.copy()
+    found = np.zeros(len(d), bool)
+    steps = 48
+    for k in range(1, steps + 1):
+        s = s_max * (k / steps)
+        p = origin + d * s[:, None]
+        neg = (p[:, 2] - _height(p[:, 0], p[:, 1])) <= 0
+        newly = neg & ~found
+        hi = np.where(newly, s, hi)
+        lo = np.where(~found & ~neg, s, lo)
+        found |= neg
+    for _ in range(26):
+        mid = 0.5 * (lo + hi)
+        p = origin + d * mid[:, None]
+        neg = (p[:, 2] - _height(p[:, 0], p[:, 1])) <= 0
+        hi = np.where(neg, mid, hi)
+        lo = np.where(neg, lo, mid)
+    return 0.5 * (lo + hi)
+
+
+def _scan_normals(p):
+    eps = 1e-4
+    ground = _height(p[:, 0], p[:, 1]) <= -0.12 + 1e-9
+    dzx = (_height(p[:, 0] + eps, p[:, 1]) - _height(p[:, 0] - eps, p[:, 1])) / (2 * eps)
+    dzy = (_height(p[:, 0], p[:, 1] + eps) - _height(p[:, 0], p[:, 1] - eps)) / (2 * eps)
+    n = np.stack([-dzx, -dzy, np.ones(len(p))], 1)
+    n[ground] = [0.0, 0.0, 1.0]
+    return n / np.linalg.norm(n, axis=1, keepdims=True)
+
+
 def c5_scan(n=8_000_000, seed=0xC5, rings=64):
-    """Scan-like: `rings` elevation rings x (n/rings) azimuth samples from a sensor above the C4 surface;
-    rays hit the height field (solved by fixed-point iteration on the ray parameter) or a ground plane
-    z = -0.2; range noise sigma = 1e-3.  Density falls off with range as in a real sweep."""
+    """C5, scan-like: a sensor 1.2 above the (periodically extended) C4 height field sweeps `rings`
+    cones (5..40 deg off nadir) x n/rings azimuth samples; rays are cast onto the surface, which is
+    clipped from below by a ground plane; range noise sigma = 1e-3.  Inner rings are much denser than
+    outer ones (same sample count on a smaller circle), as in a real sweep.  The target is the same
+    sweep half an azimuth step later (different sample points) moved by 2 deg + small t."""
     per = n // rings
     n = per * rings
+    origin = np.array([0.5, 0.5, 1.2])
     ring = np.repeat(np.arange(rings), per)
-    az = 2 * np.pi * (np.tile(np.arange(per), rings) + uniform01(seed, n, 0)) / per
-    elev = np.deg2rad(-35.0 + 30.0 * (ring + uniform01(seed, n, 1)) / rings)      # -35 .. -5 deg
-    origin = np.array([0.5, 0.5, 0.45])
-    d = np.stack([np.cos(elev) * np.cos(az), np.cos(elev) * np.sin(az), np.sin(elev)], 1)
-    # ground plane hit
-    s = (-0.2 - origin[2]) / d[:, 2]
-    for _ in range(12):   # refine against the height field where the ray lands inside [0,1)^2
-        p = origin + d * s[:, None]
-        inside = (p[:, 0] >= 0) & (p[:, 0] < 1) & (p[:, 1] >= 0) & (p[:, 1] < 1)
-        zs = _surface(np.clip(p[:, 0], 0, 1), np.clip(p[:, 1], 0, 1))[0][:, 2]
-        s_new = (zs - origin[2]) / d[:, 2]
-        s = np.where(inside, 0.5 * s + 0.5 * s_new, s)
-    noise = 1e-3 * np.sqrt(-2 * np.log(1 - uniform01(seed, n, 2))) * np.cos(2 * np.pi * uniform01(seed, n, 3))
-    p = origin + d * (s + noise)[:, None]
-    inside = (p[:, 0] >= 0) & (p[:, 0] < 1) & (p[:, 1] >= 0) & (p[:, 1] < 1)
-    nrm = np.where(inside[:, None], _surface(np.clip(p[:, 0], 0, 1), np.clip(p[:, 1], 0, 1))[1], np.array([0.0, 0.0, 1.0]))
+    az_idx = np.tile(np.arange(per), rings)
+
+    def sweep(sd, phase):
+        az = 2 * np.pi * (az_idx + phase + 0.3 * uniform01(sd, n, 0)) / per
+        polar = np.deg2rad(5.0 + 35.0 * (ring + uniform01(sd, n, 1)) / rings)
+        d = np.stack([np.sin(polar) * np.cos(az), np.sin(polar) * np.sin(az), -np.cos(polar)], 1)
+        s = _raycast(origin, d)
+        clean = origin + d * s[:, None]
+        noise = 1e-3 * np.sqrt(-2 * np.log(1 - uniform01(sd, n, 2))) * np.cos(2 * np.pi * uniform01(sd, n, 3))
+        return origin + d * (s + noise)[:, None], _scan_normals(clean)
+
+    p, nrm = sweep(seed, 0.0)
+    p2, n2 = sweep(seed + 1, 0.5)
     R = rotation(2.0, (1, 1, 5))
     t = np.array([0.003, -0.002, 0.001])
-    # target: the same sweep half an azimuth step later (different sample points), moved rigidly
-    az2 = az + np.pi / per
-    d2 = np.stack([np.cos(elev) * np.cos(az2), np.cos(elev) * np.sin(az2), np.sin(elev)], 1)
-    s2 = (-0.2 - origin[2]) / d2[:, 2]
-    for _ in range(12):
-        p2 = origin + d2 * s2[:, None]
-        in2 = (p2[:, 0] >= 0) & (p2[:, 0] < 1) & (p2[:, 1] >= 0) & (p2[:, 1] < 1)
-        zs = _surface(np.clip(p2[:, 0], 0, 1), np.clip(p2[:, 1], 0, 1))[0][:, 2]
-        s2 = np.where(in2, 0.5 * s2 + 0.5 * (zs - origin[2]) / d2[:, 2], s2)
-    noise2 = 1e-3 * np.sqrt(-2 * np.log(1 - uniform01(seed + 1, n, 2))) * np.cos(2 * np.pi * uniform01(seed + 1, n, 3))
-    p2 = origin + d2 * (s2 + noise2)[:, None]
-    in2 = (p2[:, 0] >= 0) & (p2[:, 0] < 1) & (p2[:, 1] >= 0) & (p2[:, 1] < 1)
-    n2 = np.where(in2[:, None], _surface(np.clip(p2[:, 0], 0, 1), np.clip(p2[:, 1], 0, 1))[1], np.array([0.0, 0.0, 1.0]))
     return dict(src=p.astype(np.float32), src_n=nrm.astype(np.float32), tgt=(p2 @ R.T + t).astype(np.float32),
                 tgt_n=(n2 @ R.T).astype(np.float32), truth=rigid4(R, t))
 
