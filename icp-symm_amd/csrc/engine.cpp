@@ -429,6 +429,12 @@ int symmicp_set_target(symmicp_ctx *c, const float *xyz, size_t xr, size_t xc, c
     }
     st = build_index(c, c->tgt, c->n_t, /*want_grid=*/true, c->tq, c->tn, &c->boxes, &c->cells, &c->ix, &c->st.grid_level, &c->st.tree_levels);
     if (st != SYMMICP_OK) return st;
+    if (std::getenv("SYMMICP_DEBUG_COUNTERS")) {
+        unsigned long long *dbg = nullptr;
+        HIP_TRY(c, hipMalloc((void **)&dbg, 8 * sizeof(unsigned long long)));
+        HIP_TRY(c, hipMemset(dbg, 0, 8 * sizeof(unsigned long long)));
+        c->ix.dbg = dbg;
+    }
     c->have_index = true;
     c->st.build_ms = (now_s() - t1) * 1e3;
     return SYMMICP_OK;
@@ -536,6 +542,12 @@ static int run_pass(symmicp_ctx *c, const float Xapply[16], bool from_cur, bool 
     }
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     HIP_TRY(c, hipGetLastError());
+    if (c->ix.dbg) {
+        unsigned long long h[8];
+        hipMemcpy(h, c->ix.dbg, sizeof(h), hipMemcpyDeviceToHost);
+        hipMemset(c->ix.dbg, 0, sizeof(h));
+        std::fprintf(stderr, "[symmicp dbg] pass %lld: walk=%llu cells=%llu loose_cells_sum=%llu\n", (long long)c->st.passes, h[0], h[1], h[2]);
+    }
     std::memcpy(c->last.s, c->h_sums, sizeof(double) * kNSum);
     if (c->timing) {
         float ms = 0.f;

@@ -195,114 +195,222 @@ struct Best {
 
 __device__ __forceinline__ void test_point(Best &b, const float4 &q, int32_t pos, float px, float py, float pz)
 {
-    float d2 = dist2(px, py, pz, q.x, q.y, q.z);
-    int32_t row = __float_as_int(q.w);
-    if (d2 < b.d2 || (d2 == b.d2 && row < b.row)) { b.d2 = d2; b.pos = pos; b.row = row; }
+    const float d2 = dist2(px, py, pz, q.x, q.y, q.z);
+    if (d2 <= b.d2) {                                  // rarely taken: most candidates are not better
+        const int32_t row = __float_as_int(q.w);
+        if (d2 < b.d2 || row < b.row) { b.d2 = d2; b.pos = pos; b.row = row; }
+    }
 }
+
+__device__ __forceinline__ void scan_leaf(const TargetIndex &ix, uint32_t leaf, float px, float py, float pz, Best &b)
+{
+    const uint32_t j0 = leaf * kLeaf;
+    if (j0 + kLeaf <= ix.n) {
+        float4 q[kLeaf];
+#pragma unroll
+        for (int k = 0; k < kLeaf; k++) q[k] = ix.tq[j0 + k];      // 128 B, one line: all loads in flight together
+#pragma unroll
+        for (int k = 0; k < kLeaf; k++) test_point(b, q[k], (int32_t)(j0 + k), px, py, pz);
+    } else {
+        for (uint32_t j = j0; j < ix.n; j++) test_point(b, ix.tq[j], (int32_t)j, px, py, pz);
+    }
+}
+
+// ---- near-first exact walk of the implicit 8-ary box tree -----------------------------------------
+// Node (L, i) has children (L-1, 8i+c).  Expanding a node loads its 8 child boxes together (256 B
+// contiguous), keeps the children whose box is not farther than the current best, and SORTS them by
+// box distance with a 19-comparator network on packed keys (distance bits with the low 3 bits replaced
+// by the child number).  The nearest child is entered first; the order of the remaining ones is kept
+// as a list of 4-bit child numbers in one register per level (a register "stack" of at most 8 levels,
+// shifted on push/pop: no scratch, no LDS).  When the walk comes back to a sibling its box is tested
+// again against the (now smaller) best, and because the list is sorted the first box that is too far
+// ends the whole level.  The first root-to-leaf descent therefore finds a near-optimal candidate and
+// everything after it is pruned hard.
+constexpr uint32_t kListEmpty = 0xFFFFFFFFu;
+
+struct ListStack {
+    uint32_t s[8];
+    __device__ __forceinline__ void push(uint32_t w)
+    {
+#pragma unroll
+        for (int k = 7; k > 0; k--) s[k] = s[k - 1];
+        s[0] = w;
+    }
+    __device__ __forceinline__ void pop()
+    {
+#pragma unroll
+        for (int k = 0; k < 7; k++) s[k] = s[k + 1];
+        s[7] = kListEmpty;
+    }
+};
+
+#define SYMMICP_CE(a, b) { const uint32_t lo_ = min(k[a], k[b]); const uint32_t hi_ = max(k[a], k[b]); k[a] = lo_; k[b] = hi_; }
+
+// sorted keys of the children of one node that can still hold something not farther than `best`
+__device__ __forceinline__ void sorted_child_keys(const float4 *__restrict__ bx, int nchild, float px, float py, float pz,
+                                                  float best, uint32_t k[kFan])
+{
+    float4 lo[kFan], hi[kFan];
+#pragma unroll
+    for (int c = 0; c < kFan; c++)
+        if (c < nchild) { lo[c] = bx[2 * c]; hi[c] = bx[2 * c + 1]; }
+#pragma unroll
+    for (int c = 0; c < kFan; c++) {
+        k[c] = kListEmpty;
+        if (c < nchild && lo[c].x <= hi[c].x) {
+            const float d = boxdist2(px, py, pz, lo[c], hi[c]);
+            if (d <= best) k[c] = (__float_as_uint(d) & ~7u) | (uint32_t)c;
+        }
+    }
+    SYMMICP_CE(0, 2) SYMMICP_CE(1, 3) SYMMICP_CE(4, 6) SYMMICP_CE(5, 7)
+    SYMMICP_CE(0, 4) SYMMICP_CE(1, 5) SYMMICP_CE(2, 6) SYMMICP_CE(3, 7)
+    SYMMICP_CE(0, 1) SYMMICP_CE(2, 3) SYMMICP_CE(4, 5) SYMMICP_CE(6, 7)
+    SYMMICP_CE(2, 4) SYMMICP_CE(3, 5)
+    SYMMICP_CE(1, 4) SYMMICP_CE(3, 6)
+    SYMMICP_CE(1, 2) SYMMICP_CE(3, 4) SYMMICP_CE(5, 6)
+}
+
+__device__ __forceinline__ void tree_walk_nf(const TargetIndex &ix, float px, float py, float pz, Best &b)
+{
+    ListStack st;
+#pragma unroll
+    for (int q = 0; q < 8; q++) st.s[q] = kListEmpty;
+    int L = ix.top + 1;            // virtual root above the top level
+    uint32_t i = 0;
+    bool expand = true;
+    while (true) {
+        if (expand) {
+            const int cl = L - 1;
+            const uint32_t cbase = i << 3;
+            uint32_t k[kFan];
+            sorted_child_keys(ix.boxes + 2 * ((size_t)ix.level_off[cl] + cbase), (L == ix.top + 1) ? (int)ix.ntop : kFan,
+                              px, py, pz, b.d2, k);
+            if (cl == 0) {
+                // children are leaves: scan them nearest first; a sorted key already beyond best ends the node
+#pragma unroll
+                for (int q = 0; q < kFan; q++) {
+                    if (k[q] == kListEmpty) break;
+                    if (__uint_as_float(k[q] & ~7u) > b.d2) break;
+                    scan_leaf(ix, cbase + (k[q] & 7u), px, py, pz, b);
+                }
+                // node (L, i) finished
+            } else if (k[0] != kListEmpty) {
+                uint32_t w = 0;
+#pragma unroll
+                for (int q = 1; q < kFan; q++) w |= ((k[q] == kListEmpty) ? 0xFu : (k[q] & 7u)) << (4 * (q - 1));
+                w |= 0xF0000000u;
+                st.push(w);                      // remaining children of (L, i), nearest first
+                L = cl;
+                i = cbase + (k[0] & 7u);
+                continue;                        // expand the nearest child
+            }
+        }
+        // (L, i) is finished: next sibling from the list of level L, else climb
+        if (L > ix.top) break;
+        const uint32_t w = st.s[0];
+        const uint32_t c = w & 0xFu;
+        if (c == 0xFu) {                         // level exhausted -> parent finished
+            st.pop();
+            i >>= 3;
+            L++;
+            expand = false;
+            continue;
+        }
+        st.s[0] = (w >> 4) | 0xF0000000u;
+        const uint32_t sib = (i & ~7u) | c;
+        const float4 *__restrict__ bx = ix.boxes + 2 * ((size_t)ix.level_off[L] + sib);
+        const float d = boxdist2(px, py, pz, bx[0], bx[1]);
+        if (__uint_as_float(__float_as_uint(d) & ~7u) > b.d2) {
+            st.s[0] = kListEmpty;                // sorted: everything after it is at least as far
+            expand = false;
+            continue;
+        }
+        i = sib;
+        expand = (d <= b.d2);                    // within 8 ulp of best but beyond it: skip just this one
+    }
+}
+
+#undef SYMMICP_CE
 
 __device__ __forceinline__ void nn_search(const TargetIndex &ix, float px, float py, float pz, int32_t prev, Best &b)
 {
     b.d2 = __int_as_float(0x7f800000); b.pos = -1; b.row = 0x7fffffff;
+    // phase 0: the pair of the previous pass, if any, is a real candidate (temporal coherence)
     if (prev >= 0 && (uint32_t)prev < ix.n) test_point(b, ix.tq[prev], prev, px, py, pz);
-
-    bool proven = false;
-    if (ix.glevel > 0) {
-        float fx = (px - ix.ox) * ix.inv_h, fy = (py - ix.oy) * ix.inv_h, fz = (pz - ix.oz) * ix.inv_h;
-        const float lim = (float)ix.gdim;
-        // only queries inside (or within one cell of) the grid use it
-        if (fx >= -1.0f && fy >= -1.0f && fz >= -1.0f && fx < lim + 1.0f && fy < lim + 1.0f && fz < lim + 1.0f) {
-            int cx = min(max((int)floorf(fx), 0), ix.gdim - 1);
-            int cy = min(max((int)floorf(fy), 0), ix.gdim - 1);
-            int cz = min(max((int)floorf(fz), 0), ix.gdim - 1);
-            const float margin = 2e-3f * ix.h;
-            for (int dz = -1; dz <= 1; dz++) {
-                int z = cz + dz;
-                if (z < 0 || z >= ix.gdim) continue;
-                float zlo = ix.oz + (float)z * ix.h;
-                float gz = fmaxf(fmaxf(zlo - pz, pz - (zlo + ix.h)) - margin, 0.0f);
-                uint32_t mz = spread3((uint32_t)z) << 2;
-                for (int dy = -1; dy <= 1; dy++) {
-                    int y = cy + dy;
-                    if (y < 0 || y >= ix.gdim) continue;
-                    float ylo = ix.oy + (float)y * ix.h;
-                    float gy = fmaxf(fmaxf(ylo - py, py - (ylo + ix.h)) - margin, 0.0f);
-                    uint32_t mzy = mz | (spread3((uint32_t)y) << 1);
-                    for (int dx = -1; dx <= 1; dx++) {
-                        int x = cx + dx;
-                        if (x < 0 || x >= ix.gdim) continue;
-                        float xlo = ix.ox + (float)x * ix.h;
-                        float gx = fmaxf(fmaxf(xlo - px, px - (xlo + ix.h)) - margin, 0.0f);
-                        float g2 = (gx * gx + gy * gy) + gz * gz;
+    // phase 1: every target point not farther than the candidate lies in the ball around the query;
+    // if that ball overlaps at most 3 cells per axis of the dense Morton cell table, scan those cells.
+    if (b.pos >= 0 && ix.glevel > 0) {
+        const float margin = 2e-3f * ix.h;         // cell assignment is fp32: stay conservative
+        const float gmax = (float)ix.gdim;
+        const float r = sqrtf(b.d2) * 1.000001f + margin;
+        const float lx = (px - r - ix.ox) * ix.inv_h, hx = (px + r - ix.ox) * ix.inv_h;
+        const float ly = (py - r - ix.oy) * ix.inv_h, hy = (py + r - ix.oy) * ix.inv_h;
+        const float lz = (pz - r - ix.oz) * ix.inv_h, hz = (pz + r - ix.oz) * ix.inv_h;
+        // clamp in float first (keeps the int conversion defined for huge values)
+        const int x0 = (int)floorf(fminf(fmaxf(lx, 0.0f), gmax - 1.0f)), x1 = (int)floorf(fminf(fmaxf(hx, 0.0f), gmax - 1.0f));
+        const int y0 = (int)floorf(fminf(fmaxf(ly, 0.0f), gmax - 1.0f)), y1 = (int)floorf(fminf(fmaxf(hy, 0.0f), gmax - 1.0f));
+        const int z0 = (int)floorf(fminf(fmaxf(lz, 0.0f), gmax - 1.0f)), z1 = (int)floorf(fminf(fmaxf(hz, 0.0f), gmax - 1.0f));
+        if (x1 - x0 <= 2 && y1 - y0 <= 2 && z1 - z0 <= 2) {
+            for (int z = z0; z <= z1; z++) {
+                const float zlo = ix.oz + (float)z * ix.h;
+                const float gz = fmaxf(fmaxf(zlo - pz, pz - (zlo + ix.h)) - margin, 0.0f);
+                const uint32_t mz = spread3((uint32_t)z) << 2;
+                for (int y = y0; y <= y1; y++) {
+                    const float ylo = ix.oy + (float)y * ix.h;
+                    const float gy = fmaxf(fmaxf(ylo - py, py - (ylo + ix.h)) - margin, 0.0f);
+                    const uint32_t mzy = mz | (spread3((uint32_t)y) << 1);
+                    for (int x = x0; x <= x1; x++) {
+                        const float xlo = ix.ox + (float)x * ix.h;
+                        const float gx = fmaxf(fmaxf(xlo - px, px - (xlo + ix.h)) - margin, 0.0f);
+                        const float g2 = (gx * gx + gy * gy) + gz * gz;
                         if (g2 > b.d2) continue;
-                        uint2 r = ix.cells[mzy | spread3((uint32_t)x)];
-                        for (uint32_t j = r.x; j < r.y; j++) test_point(b, ix.tq[j], (int32_t)j, px, py, pz);
+                        const uint2 rng = ix.cells[mzy | spread3((uint32_t)x)];
+                        for (uint32_t j = rng.x; j < rng.y; j++) test_point(b, ix.tq[j], (int32_t)j, px, py, pz);
                     }
                 }
             }
-            // every point of cells [c-1, c+1] has been seen (or was provably farther than best).
-            // Unseen points lie beyond the faces of that block; faces on the grid edge bound nothing.
-            float bound = __int_as_float(0x7f800000);
-            bool any = false;
-            if (cx - 1 > 0) { bound = fminf(bound, px - (ix.ox + (float)(cx - 1) * ix.h)); any = true; }
-            if (cy - 1 > 0) { bound = fminf(bound, py - (ix.oy + (float)(cy - 1) * ix.h)); any = true; }
-            if (cz - 1 > 0) { bound = fminf(bound, pz - (ix.oz + (float)(cz - 1) * ix.h)); any = true; }
-            if (cx + 1 < ix.gdim - 1) { bound = fminf(bound, (ix.ox + (float)(cx + 2) * ix.h) - px); any = true; }
-            if (cy + 1 < ix.gdim - 1) { bound = fminf(bound, (ix.oy + (float)(cy + 2) * ix.h) - py); any = true; }
-            if (cz + 1 < ix.gdim - 1) { bound = fminf(bound, (ix.oz + (float)(cz + 2) * ix.h) - pz); any = true; }
-            if (!any) {
-                proven = (b.pos >= 0);   // the block covers the whole grid
-            } else {
-                bound -= margin;
-                proven = (b.pos >= 0) && bound > 0.0f && b.d2 < bound * bound * 0.99999f;
-            }
+            if (ix.dbg) atomicAdd(ix.dbg + 1, 1ull);
+            return;
         }
+        if (ix.dbg) atomicAdd(ix.dbg + 2, (unsigned long long)(x1 - x0 + 1) * (y1 - y0 + 1) * (z1 - z0 + 1));
     }
-    if (proven) return;
-
-    // tree walk.  Node (level, i); children of (level, i) are (level-1, 8i .. 8i+7).
-    int level = ix.top;
-    uint32_t i = 0;
-    while (true) {
-        const float4 *bx = ix.boxes + 2 * ((size_t)ix.level_off[level] + i);
-        float4 lo = bx[0], hi = bx[1];
-        float d = boxdist2(px, py, pz, lo, hi);
-        bool hit = (d <= b.d2) && (lo.x <= hi.x);
-        if (hit && level > 0) {
-            level--; i <<= 3;
-            continue;
-        }
-        if (hit) {
-            uint32_t j0 = i * kLeaf, j1 = min(j0 + kLeaf, ix.n);
-            for (uint32_t j = j0; j < j1; j++) test_point(b, ix.tq[j], (int32_t)j, px, py, pz);
-        }
-        i++;
-        while ((i & (kFan - 1)) == 0 && level < ix.top) { i >>= 3; level++; }
-        if (level == ix.top && i >= ix.ntop) break;
-    }
+    // phase 2: no candidate, or a loose one -> near-first tree walk (exact for any bound)
+    if (ix.dbg) atomicAdd(ix.dbg + 0, 1ull);
+    tree_walk_nf(ix, px, py, pz, b);
 }
 
+// Two sweeps over this thread's points inside ONE launch: sweep A searches (registers: walk state),
+// sweep B accumulates (registers: 37 fp64 sums).  Keeping them apart lets the two register sets
+// overlap instead of adding up, which is worth one more wave per SIMD.
 __global__ __launch_bounds__(kPassThreads) void k_pass_tree(PassArgs a, TargetIndex ix)
 {
-    Acc acc; acc_zero(acc);
     const uint32_t stride = gridDim.x * blockDim.x;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += stride) {
-        float x = a.in.x[i], y = a.in.y[i], z = a.in.z[i];
-        float nx = a.in.nx[i], ny = a.in.ny[i], nz = a.in.nz[i];
-        float px = xf_row(a.X.m + 0, x, y, z, 1.0f), py = xf_row(a.X.m + 4, x, y, z, 1.0f), pz = xf_row(a.X.m + 8, x, y, z, 1.0f);
-        float npx = xf_row(a.X.m + 0, nx, ny, nz, a.X.nrm_w), npy = xf_row(a.X.m + 4, nx, ny, nz, a.X.nrm_w),
-              npz = xf_row(a.X.m + 8, nx, ny, nz, a.X.nrm_w);
+    const uint32_t first = blockIdx.x * blockDim.x + threadIdx.x;
+    for (uint32_t i = first; i < a.n; i += stride) {
+        const float x = a.in.x[i], y = a.in.y[i], z = a.in.z[i];
+        const float px = xf_row(a.X.m + 0, x, y, z, 1.0f), py = xf_row(a.X.m + 4, x, y, z, 1.0f), pz = xf_row(a.X.m + 8, x, y, z, 1.0f);
+        Best b;
+        nn_search(ix, px, py, pz, a.pos_prev ? a.pos_prev[i] : -1, b);
+        a.pos_out[i] = b.pos;
+        a.d2_out[i] = b.d2;
+    }
+    Acc acc; acc_zero(acc);
+    for (uint32_t i = first; i < a.n; i += stride) {
+        const float x = a.in.x[i], y = a.in.y[i], z = a.in.z[i];
+        const float nx = a.in.nx[i], ny = a.in.ny[i], nz = a.in.nz[i];
+        const float px = xf_row(a.X.m + 0, x, y, z, 1.0f), py = xf_row(a.X.m + 4, x, y, z, 1.0f), pz = xf_row(a.X.m + 8, x, y, z, 1.0f);
+        const float npx = xf_row(a.X.m + 0, nx, ny, nz, a.X.nrm_w), npy = xf_row(a.X.m + 4, nx, ny, nz, a.X.nrm_w),
+                    npz = xf_row(a.X.m + 8, nx, ny, nz, a.X.nrm_w);
         if (a.writeback) {
             a.out.x[i] = px; a.out.y[i] = py; a.out.z[i] = pz;
             a.out.nx[i] = npx; a.out.ny[i] = npy; a.out.nz[i] = npz;
         }
-        Best b;
-        nn_search(ix, px, py, pz, a.pos_prev ? a.pos_prev[i] : -1, b);
-        if (a.pos_out) a.pos_out[i] = b.pos;
-        if (a.d2_out) a.d2_out[i] = b.d2;
-        if (b.pos < 0) continue;
-        if (a.max_d2 > 0.0f && b.d2 > a.max_d2) continue;
-        float4 q = ix.tq[b.pos], nq = ix.tn[b.pos];
-        acc_pair(acc, px, py, pz, npx, npy, npz, q.x, q.y, q.z, nq.x, nq.y, nq.z, b.d2, a.pivot);
+        const int32_t pos = a.pos_out[i];          // written by this same thread in sweep A
+        const float d2 = a.d2_out[i];
+        if (pos < 0) continue;
+        if (a.max_d2 > 0.0f && d2 > a.max_d2) continue;
+        const float4 q = ix.tq[pos], nq = ix.tn[pos];
+        acc_pair(acc, px, py, pz, npx, npy, npz, q.x, q.y, q.z, nq.x, nq.y, nq.z, d2, a.pivot);
     }
     acc_block_reduce_store(acc, a.partials + (size_t)blockIdx.x * kNSum);
 }

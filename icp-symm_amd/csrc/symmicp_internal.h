@@ -50,6 +50,7 @@ struct TargetIndex {
     int32_t gdim;            // 1 << glevel
     float ox, oy, oz;        // grid origin (target bbox min)
     float h, inv_h;          // cell edge at glevel
+    unsigned long long *dbg; // optional debug counters (SYMMICP_DEBUG_COUNTERS=1), else null
 };
 
 struct PassArgs {
