@@ -456,10 +456,10 @@ int symmicp_set_source(symmicp_ctx *c, const float *xyz, size_t xr, size_t xc, c
     soa_from_block(full, n, fs);
     c->n_s_total = (uint32_t)n;
     // contiguous share of the (sorted) source for this rank
-    const uint64_t b0 = (uint64_t)n * (uint64_t)c->rank / (uint64_t)c->nranks;
-    const uint64_t b1 = (uint64_t)n * (uint64_t)(c->rank + 1) / (uint64_t)c->nranks;
+    size_t b0 = 0, bc = 0;
+    symmicp_shard_range(n, c->nranks, c->rank, &b0, &bc);
     c->src_off = (uint32_t)b0;
-    c->n_loc = (uint32_t)(b1 - b0);
+    c->n_loc = (uint32_t)bc;
     const uint32_t nl = c->n_loc > 0 ? c->n_loc : 1;
     HIP_TRY(c, hipMalloc((void **)&c->src0_block, sizeof(float) * 6 * nl));
     HIP_TRY(c, hipMalloc((void **)&c->cur_block, sizeof(float) * 6 * nl));
@@ -777,12 +777,23 @@ int symmicp_comm_get_unique_id(void *out128)
     return SYMMICP_OK;
 }
 
+int symmicp_shard_range(size_t n, int nranks, int rank, size_t *begin, size_t *count)
+{
+    if (!begin || !count || nranks < 1 || rank < 0 || rank >= nranks) return SYMMICP_ERR_ARG;
+    const uint64_t b0 = (uint64_t)n * (uint64_t)rank / (uint64_t)nranks;
+    const uint64_t b1 = (uint64_t)n * (uint64_t)(rank + 1) / (uint64_t)nranks;
+    *begin = (size_t)b0;
+    *count = (size_t)(b1 - b0);
+    return SYMMICP_OK;
+}
+
 int symmicp_comm_init_rank(symmicp_ctx *c, int nranks, int rank, const void *uid)
 {
     if (!c) return SYMMICP_ERR_ARG;
     if (nranks < 1 || rank < 0 || rank >= nranks) return fail(c, SYMMICP_ERR_ARG, "bad rank/nranks");
     if (c->src0_block) return fail(c, SYMMICP_ERR_STATE, "attach the communicator before symmicp_set_source");
-    if (nranks == 1) { c->nranks = 1; c->rank = 0; return SYMMICP_OK; }
+    // a 1-rank communicator is legal RCCL; it is only built on request (exercises the RCCL path on one GPU)
+    if (nranks == 1 && !std::getenv("SYMMICP_FORCE_COMM")) { c->nranks = 1; c->rank = 0; return SYMMICP_OK; }
     if (!uid) return fail(c, SYMMICP_ERR_ARG, "null unique id");
     if (!g_rccl.load()) return fail(c, SYMMICP_ERR_COMM, g_rccl.err);
     HIP_TRY(c, hipSetDevice(c->device));

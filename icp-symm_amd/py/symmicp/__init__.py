@@ -67,7 +67,7 @@ EXPORTS = [
     "symmicp_version", "symmicp_set_source", "symmicp_set_target", "symmicp_align", "symmicp_begin", "symmicp_step",
     "symmicp_get_transform", "symmicp_get_pivot", "symmicp_get_correspondences", "symmicp_get_source",
     "symmicp_local_source_count", "symmicp_local_source_offset", "symmicp_solve", "symmicp_comm_get_unique_id",
-    "symmicp_comm_init_rank", "symmicp_get_stats", "symmicp_reset_stats", "symmicp_enable_timing",
+    "symmicp_comm_init_rank", "symmicp_shard_range", "symmicp_get_stats", "symmicp_reset_stats", "symmicp_enable_timing",
     "symmicp_pcd_read", "symmicp_pcd_write", "symmicp_estimate_normals",
 ]
 
@@ -121,6 +121,7 @@ def lib():
     L.symmicp_solve.argtypes = [C.c_int, C.POINTER(Sums), fp, fp, fp, fp, fp, fp, fp]
     L.symmicp_comm_get_unique_id.argtypes = [vp]
     L.symmicp_comm_init_rank.argtypes = [vp, C.c_int, C.c_int, vp]
+    L.symmicp_shard_range.argtypes = [C.c_size_t, C.c_int, C.c_int, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
     L.symmicp_get_stats.argtypes = [vp, C.POINTER(Stats)]
     L.symmicp_reset_stats.argtypes = [vp]
     L.symmicp_enable_timing.argtypes = [vp, C.c_int]
@@ -206,6 +207,14 @@ def estimate_normals(xyz, k=10, viewpoint=(0.0, 0.0, 0.0), device=-1):
     if st != OK:
         raise SymmIcpError(st, "estimate_normals")
     return nrm, curv
+
+
+def shard_range(n, nranks, rank):
+    b, c = C.c_size_t(0), C.c_size_t(0)
+    st = lib().symmicp_shard_range(n, nranks, rank, C.byref(b), C.byref(c))
+    if st != OK:
+        raise SymmIcpError(st, "shard_range")
+    return int(b.value), int(c.value)
 
 
 def comm_get_unique_id():

@@ -166,6 +166,9 @@ int symmicp_estimate_normals(int device, const float *xyz, size_t row_stride, si
  * then every rank calls comm_init_rank BEFORE set_source.  One RCCL all-reduce of
  * SYMMICP_NSUM doubles per pass. */
 int symmicp_comm_get_unique_id(void *out128);
+/* the contiguous share [begin, begin+count) of n (Morton-sorted) source rows that `rank` of `nranks` owns;
+ * pure host arithmetic, the same partition symmicp_set_source applies. */
+int symmicp_shard_range(size_t n, int nranks, int rank, size_t *begin, size_t *count);
 int symmicp_comm_init_rank(symmicp_ctx *ctx, int nranks, int rank, const void *unique_id128);
 
 /* ---- measurement helpers ------------------------------------------------ */

@@ -101,3 +101,28 @@ def test_pcd_io_roundtrip(sym, oracle, tmp_path):
         assert np.array_equal(a2, xyz[:100]) and np.array_equal(b2, n)
     with pytest.raises(sym.SymmIcpError):
         sym.pcd_read(str(tmp_path / "missing.pcd"))
+
+
+def test_reference_main_cpp_compiles_unchanged_against_the_dropin(sym, tmp_path):
+    """The reference's own driver (ICP/main.cpp), byte for byte, builds against include/myicp.h +
+    include/stdafx.h + the pcl:: stand-in and links with libsymmicp.  Only where /root/reference is
+    mounted (it is not on the GPU box); the file is copied to a temp dir outside the repo so that its
+    quoted includes resolve to this repo's headers instead of the Windows-only originals."""
+    import shutil
+    import subprocess
+    ref = "/root/reference/ICP/main.cpp"
+    if not os.path.exists(ref):
+        pytest.skip("reference not mounted")
+    shutil.copy(ref, tmp_path / "main.cpp")
+    exe = tmp_path / "ref_main"
+    libdir = os.path.dirname(sym.LIB_PATH)
+    r = subprocess.run(["g++", "-std=c++17", "-w", "-I", os.path.join(ROOT, "include"), str(tmp_path / "main.cpp"), "-o", str(exe),
+                        "-L", libdir, "-lsymmicp", "-Wl,-rpath," + libdir], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    import torch
+    if not torch.cuda.is_available():
+        # no GPU here: the drop-in must fail loudly, not fall back to a CPU path
+        shutil.copy(os.path.join(GOLDEN, "cat.pcd"), tmp_path / "cat.pcd")
+        shutil.copy(os.path.join(GOLDEN, "cat_out.pcd"), tmp_path / "cat_out.pcd")
+        r = subprocess.run([str(exe)], cwd=tmp_path, capture_output=True, text=True, timeout=120)
+        assert "no usable gfx950 HIP device" in r.stderr and "Result transform" not in r.stdout
