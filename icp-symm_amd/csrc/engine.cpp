@@ -94,6 +94,7 @@ struct symmicp_ctx {
     int32_t *pos = nullptr;
     float *d2 = nullptr;
     unsigned long long *best64 = nullptr;
+    uint32_t *worklist = nullptr, *wl_count = nullptr;
     // reduction
     int pass_blocks = 0;
     double *partials = nullptr, *d_sums = nullptr, *h_sums = nullptr, *h_sums_dev = nullptr;
@@ -211,7 +212,8 @@ static void free_target(symmicp_ctx *c)
 
 static void free_source(symmicp_ctx *c)
 {
-    hipFree(c->src0_block); hipFree(c->cur_block); hipFree(c->src_order); hipFree(c->pos); hipFree(c->d2); hipFree(c->best64);
+    hipFree(c->src0_block); hipFree(c->cur_block); hipFree(c->src_order); hipFree(c->pos); hipFree(c->d2); hipFree(c->best64); hipFree(c->worklist); hipFree(c->wl_count);
+    c->worklist = c->wl_count = nullptr;
     c->src0_block = c->cur_block = nullptr; c->src_order = nullptr; c->pos = nullptr; c->d2 = nullptr; c->best64 = nullptr;
     c->n_loc = c->n_s_total = c->src_off = 0;
 }
@@ -489,6 +491,10 @@ int symmicp_set_source(symmicp_ctx *c, const float *xyz, size_t xr, size_t xc, c
     HIP_TRY(c, hipMalloc((void **)&c->pos, sizeof(int32_t) * nl));
     HIP_TRY(c, hipMalloc((void **)&c->d2, sizeof(float) * nl));
     if (c->cfg.corr == SYMMICP_CORR_BRUTE) HIP_TRY(c, hipMalloc((void **)&c->best64, sizeof(unsigned long long) * nl));
+    if (c->cfg.corr == SYMMICP_CORR_TREE) {
+        HIP_TRY(c, hipMalloc((void **)&c->worklist, sizeof(uint32_t) * 2 * nl));      // work list + overflow list
+        HIP_TRY(c, hipMalloc((void **)&c->wl_count, 2 * sizeof(uint32_t)));
+    }
     HIP_TRY(c, hipGetLastError());
     c->st.upload_ms += (now_s() - t0) * 1e3;
     return SYMMICP_OK;
@@ -530,7 +536,14 @@ static int run_pass(symmicp_ctx *c, const float Xapply[16], bool from_cur, bool 
         launch_pass_indexed(a, c->tq, c->tn, blocks, c->stream);
         break;
     default:
-        launch_pass_tree(a, c->ix, blocks, c->stream);
+        if (std::getenv("SYMMICP_FUSED")) {
+            launch_pass_tree(a, c->ix, blocks, c->stream);
+        } else {
+            // the accumulate kernel is streaming: 8 blocks per CU worth of grid, a multiple of 8 for the XCD remap
+            int ab = blocks < 2048 ? ((blocks + 7) / 8) * 8 : 2048;
+            c->pass_blocks = blocks = ab;
+            launch_pass_tree_split(a, c->ix, c->worklist, c->wl_count, ab, c->stream);
+        }
         break;
     }
     if (c->timing) hipEventRecord(c->ev1, c->stream);

@@ -85,7 +85,8 @@ __device__ __forceinline__ void acc_pair(Acc &a, float px, float py, float pz, f
 }
 
 // block reduction: wave64 shuffle tree, then LDS across waves; fixed order -> deterministic
-__device__ __forceinline__ void acc_block_reduce_store(Acc &a, double *partials_row)
+// record k of block b lands at partials[k * nblocks + b] (transposed: the final reduce reads it coalesced)
+__device__ __forceinline__ void acc_block_reduce_store(Acc &a, double *partials, uint32_t nblocks)
 {
     __shared__ double red[(kPassThreads / 64) * kNSum];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -103,7 +104,7 @@ __device__ __forceinline__ void acc_block_reduce_store(Acc &a, double *partials_
 #pragma unroll
             for (int w = 0; w < kPassThreads / 64; w++) s += red[w * kNSum + threadIdx.x];
         }
-        partials_row[threadIdx.x] = s;
+        partials[(size_t)threadIdx.x * nblocks + blockIdx.x] = s;
     }
 }
 
@@ -132,7 +133,7 @@ __global__ __launch_bounds__(kPassThreads) void k_pass_identity(PassArgs a, Clou
         if (a.max_d2 > 0.0f && d2 > a.max_d2) continue;
         acc_pair(acc, px, py, pz, npx, npy, npz, qx, qy, qz, tgt.nx[j], tgt.ny[j], tgt.nz[j], d2, a.pivot);
     }
-    acc_block_reduce_store(acc, a.partials + (size_t)blockIdx.x * kNSum);
+    acc_block_reduce_store(acc, a.partials, gridDim.x);
 }
 
 // ---------------------------------------------------------------------------
@@ -165,7 +166,7 @@ __global__ __launch_bounds__(kPassThreads) void k_pass_indexed(PassArgs a, const
         float4 q = tq[j], nq = tn[j];
         acc_pair(acc, px, py, pz, npx, npy, npz, q.x, q.y, q.z, nq.x, nq.y, nq.z, d2, a.pivot);
     }
-    acc_block_reduce_store(acc, a.partials + (size_t)blockIdx.x * kNSum);
+    acc_block_reduce_store(acc, a.partials, gridDim.x);
 }
 
 // ---------------------------------------------------------------------------
@@ -412,31 +413,280 @@ __global__ __launch_bounds__(kPassThreads) void k_pass_tree(PassArgs a, TargetIn
         const float4 q = ix.tq[pos], nq = ix.tn[pos];
         acc_pair(acc, px, py, pz, npx, npy, npz, q.x, q.y, q.z, nq.x, nq.y, nq.z, d2, a.pivot);
     }
-    acc_block_reduce_store(acc, a.partials + (size_t)blockIdx.x * kNSum);
+    acc_block_reduce_store(acc, a.partials, gridDim.x);
 }
 
 // ---------------------------------------------------------------------------
-// final reduce: [blocks][40] -> [40], fixed order.  1000 threads = 40 sums x 25 strands.
-// Writes the device record and, when given, a host-mapped copy (single-GPU fast path).
+// The same pass as three lean kernels (default for TREE correspondences):
+//   k_search_fast  1 point per thread: transform, previous-pair bound, cell scan.  ~40 VGPRs -> 8 waves
+//                  per SIMD to hide the dependent gathers.  Queries it cannot finish (no previous pair,
+//                  or a ball wider than 3 cells) go to a work list.
+//   k_search_walk  near-first tree walk for the work list only (compacted: every lane is a walker).
+//   k_accumulate   streaming: rows + 37 fp64 sums from the stored pairs (and the optional write-back).
+// Blocks are dealt to XCDs round-robin, so block b is remapped to a contiguous chunk of the Morton-
+// sorted source per XCD: each XCD's 4 MB L2 then serves one compact region of the target.
 // ---------------------------------------------------------------------------
-constexpr int kFinalStrands = 25;
-__global__ __launch_bounds__(1024) void k_final_reduce(const double *__restrict__ partials, int blocks,
-                                                       double *out_dev, double *out_host)
+constexpr int kWaveFrontier = 512;        // nodes per level per wave (k_search_walk_wave)
+constexpr uint32_t kWaveModeMax = 65536;  // work lists longer than this use one thread per query
+
+__device__ __forceinline__ uint32_t xcd_remap(uint32_t b, uint32_t nb_padded)
 {
-    __shared__ double red[kFinalStrands * kNSum];
-    const int t = threadIdx.x;
-    if (t < kFinalStrands * kNSum) {
-        const int k = t % kNSum, strand = t / kNSum;
-        double s = 0.0;
-        for (int b = strand; b < blocks; b += kFinalStrands) s += partials[(size_t)b * kNSum + k];
-        red[strand * kNSum + k] = s;
+    return (b & 7u) * (nb_padded >> 3) + (b >> 3);
+}
+
+__global__ __launch_bounds__(kPassThreads) void k_search_fast(PassArgs a, TargetIndex ix, uint32_t *worklist, uint32_t *wl_count)
+{
+    const uint32_t i = xcd_remap(blockIdx.x, gridDim.x) * kPassThreads + threadIdx.x;
+    if (i >= a.n) return;
+    const float x = a.in.x[i], y = a.in.y[i], z = a.in.z[i];
+    const int32_t prev = a.pos_prev ? a.pos_prev[i] : -1;
+    const float px = xf_row(a.X.m + 0, x, y, z, 1.0f), py = xf_row(a.X.m + 4, x, y, z, 1.0f), pz = xf_row(a.X.m + 8, x, y, z, 1.0f);
+    Best b;
+    b.d2 = __int_as_float(0x7f800000); b.pos = -1; b.row = 0x7fffffff;
+    if (prev >= 0 && (uint32_t)prev < ix.n) test_point(b, ix.tq[prev], prev, px, py, pz);
+    bool done = false;
+    if (b.pos >= 0 && ix.glevel > 0) {
+        const float margin = 2e-3f * ix.h;
+        const float gmax = (float)ix.gdim;
+        const float r = sqrtf(b.d2) * 1.000001f + margin;
+        const float lx = (px - r - ix.ox) * ix.inv_h, hx = (px + r - ix.ox) * ix.inv_h;
+        const float ly = (py - r - ix.oy) * ix.inv_h, hy = (py + r - ix.oy) * ix.inv_h;
+        const float lz = (pz - r - ix.oz) * ix.inv_h, hz = (pz + r - ix.oz) * ix.inv_h;
+        const int x0 = (int)floorf(fminf(fmaxf(lx, 0.0f), gmax - 1.0f)), x1 = (int)floorf(fminf(fmaxf(hx, 0.0f), gmax - 1.0f));
+        const int y0 = (int)floorf(fminf(fmaxf(ly, 0.0f), gmax - 1.0f)), y1 = (int)floorf(fminf(fmaxf(hy, 0.0f), gmax - 1.0f));
+        const int z0 = (int)floorf(fminf(fmaxf(lz, 0.0f), gmax - 1.0f)), z1 = (int)floorf(fminf(fmaxf(hz, 0.0f), gmax - 1.0f));
+        if (x1 - x0 <= 2 && y1 - y0 <= 2 && z1 - z0 <= 2) {
+            for (int zz = z0; zz <= z1; zz++) {
+                const float zlo = ix.oz + (float)zz * ix.h;
+                const float gz = fmaxf(fmaxf(zlo - pz, pz - (zlo + ix.h)) - margin, 0.0f);
+                const uint32_t mz = spread3((uint32_t)zz) << 2;
+                for (int yy = y0; yy <= y1; yy++) {
+                    const float ylo = ix.oy + (float)yy * ix.h;
+                    const float gy = fmaxf(fmaxf(ylo - py, py - (ylo + ix.h)) - margin, 0.0f);
+                    const uint32_t mzy = mz | (spread3((uint32_t)yy) << 1);
+                    for (int xx = x0; xx <= x1; xx++) {
+                        const float xlo = ix.ox + (float)xx * ix.h;
+                        const float gx = fmaxf(fmaxf(xlo - px, px - (xlo + ix.h)) - margin, 0.0f);
+                        const float g2 = (gx * gx + gy * gy) + gz * gz;
+                        if (g2 > b.d2) continue;
+                        const uint2 rng = ix.cells[mzy | spread3((uint32_t)xx)];
+                        for (uint32_t j = rng.x; j < rng.y; j++) test_point(b, ix.tq[j], (int32_t)j, px, py, pz);
+                    }
+                }
+            }
+            done = true;
+        }
     }
+    a.pos_out[i] = b.pos;            // provisional for work-list entries: the walk starts from this bound
+    a.d2_out[i] = b.d2;
+    if (!done) worklist[atomicAdd(wl_count, 1u)] = i;
+}
+
+// one thread per query.  Long work lists (far passes) come here directly; for short lists (wave mode) only
+// the overflow list of k_search_walk_wave is left.
+__global__ __launch_bounds__(kPassThreads) void k_search_walk(PassArgs a, TargetIndex ix, const uint32_t *__restrict__ worklist,
+                                                             const uint32_t *__restrict__ wl_count, const uint32_t *__restrict__ overflow,
+                                                             const uint32_t *__restrict__ ov_count)
+{
+    uint32_t count = *wl_count;
+    if (count <= kWaveModeMax) { worklist = overflow; count = *ov_count; }
+    for (uint32_t w = blockIdx.x * blockDim.x + threadIdx.x; w < count; w += gridDim.x * blockDim.x) {
+        const uint32_t i = worklist[w];
+        const float x = a.in.x[i], y = a.in.y[i], z = a.in.z[i];
+        const float px = xf_row(a.X.m + 0, x, y, z, 1.0f), py = xf_row(a.X.m + 4, x, y, z, 1.0f), pz = xf_row(a.X.m + 8, x, y, z, 1.0f);
+        Best b;
+        b.pos = a.pos_out[i]; b.d2 = a.d2_out[i]; b.row = 0x7fffffff;
+        if (b.pos >= 0) b.row = __float_as_int(ix.tq[b.pos].w);
+        tree_walk_nf(ix, px, py, pz, b);
+        a.pos_out[i] = b.pos;
+        a.d2_out[i] = b.d2;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Stragglers.  In a converged pass only a few thousand queries are left on the work list (source
+// points outside the overlap: far from the target, but with a TIGHT bound from their previous pair).
+// One thread per query would serialise ~100 dependent loads each (hundreds of microseconds for a
+// handful of waves), so when the list is short each query gets a whole WAVE: a level-synchronous
+// branch-and-bound over the same box tree.  The frontier of one level lives in LDS; a batch of 8
+// frontier nodes x 8 children is tested by the 64 lanes at once; survivors are compacted with
+// __ballot + popcount.  The pruning radius is min(best real candidate, smallest max-distance of any
+// box seen) -- a non-empty box guarantees a point within its farthest corner.  Leaves: 8 leaves x 8
+// points per batch, wave-wide argmin on (d2 bits << 32 | row).  If a frontier outgrows its LDS slot
+// the query is handed to the one-thread-per-query kernel instead (exact either way).
+// ---------------------------------------------------------------------------
+
+__device__ __forceinline__ float boxmaxdist2(float px, float py, float pz, const float4 &lo, const float4 &hi)
+{
+    float dx = fmaxf(fabsf(px - lo.x), fabsf(px - hi.x));
+    float dy = fmaxf(fabsf(py - lo.y), fabsf(py - hi.y));
+    float dz = fmaxf(fabsf(pz - lo.z), fabsf(pz - hi.z));
+    return (dx * dx + dy * dy) + dz * dz;
+}
+
+__device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        unsigned long long o = __shfl_xor(v, off, 64);
+        v = o < v ? o : v;
+    }
+    return v;
+}
+
+__device__ __forceinline__ float wave_min_f32(float v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fminf(v, __shfl_xor(v, off, 64));
+    return v;
+}
+
+__global__ __launch_bounds__(kPassThreads) void k_search_walk_wave(PassArgs a, TargetIndex ix, const uint32_t *__restrict__ worklist,
+                                                                  const uint32_t *__restrict__ wl_count, uint32_t *overflow,
+                                                                  uint32_t *ov_count)
+{
+    __shared__ uint32_t fr[kPassThreads / 64][2][kWaveFrontier];
+    const uint32_t count = *wl_count;
+    if (count > kWaveModeMax) return;           // long list: k_search_walk does it, one thread per query
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t nwaves = gridDim.x * (kPassThreads / 64);
+    const float inf = __int_as_float(0x7f800000);
+    for (uint32_t w = blockIdx.x * (kPassThreads / 64) + wave; w < count; w += nwaves) {
+        const uint32_t i = worklist[w];
+        const float x = a.in.x[i], y = a.in.y[i], z = a.in.z[i];
+        const float px = xf_row(a.X.m + 0, x, y, z, 1.0f), py = xf_row(a.X.m + 4, x, y, z, 1.0f), pz = xf_row(a.X.m + 8, x, y, z, 1.0f);
+        // wave-uniform best: key = (d2 bits << 32 | row), plus the sorted position of that row
+        int32_t bpos = a.pos_out[i];
+        float bd2 = a.d2_out[i];
+        unsigned long long bkey = ~0ull;
+        if (bpos >= 0) bkey = ((unsigned long long)__float_as_uint(bd2) << 32) | (unsigned long long)(uint32_t)__float_as_int(ix.tq[bpos].w);
+        else bd2 = inf;
+        float radius2 = bd2;                    // pruning radius: never below the true nearest distance
+        bool overflowed = false;
+        // top level: <= 8 nodes, lanes 0..7
+        uint32_t nf = 0;
+        {
+            float mind = inf, maxd = inf;
+            if (lane < (int)ix.ntop) {
+                const float4 *bx = ix.boxes + 2 * ((size_t)ix.level_off[ix.top] + lane);
+                const float4 lo = bx[0], hi = bx[1];
+                if (lo.x <= hi.x) { mind = boxdist2(px, py, pz, lo, hi); maxd = boxmaxdist2(px, py, pz, lo, hi); }
+            }
+            radius2 = fminf(radius2, wave_min_f32(maxd));
+            const bool keep = mind <= radius2 && mind < inf;
+            const unsigned long long m = __ballot(keep);
+            if (keep) fr[wave][0][__popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)lane;
+            nf = (uint32_t)__popcll(m);
+            __builtin_amdgcn_wave_barrier();
+        }
+        int cur = 0;
+        for (int L = ix.top; L >= 1 && !overflowed; L--) {
+            // expand the frontier of level L into level L-1
+            uint32_t nn = 0;
+            for (uint32_t f0 = 0; f0 < nf; f0 += 8) {
+                const uint32_t f = f0 + (uint32_t)(lane >> 3);
+                float mind = inf, maxd = inf;
+                uint32_t child = 0;
+                if (f < nf) {
+                    child = (fr[wave][cur][f] << 3) + (uint32_t)(lane & 7);
+                    const float4 *bx = ix.boxes + 2 * ((size_t)ix.level_off[L - 1] + child);
+                    const float4 lo = bx[0], hi = bx[1];
+                    if (lo.x <= hi.x) { mind = boxdist2(px, py, pz, lo, hi); maxd = boxmaxdist2(px, py, pz, lo, hi); }
+                }
+                radius2 = fminf(radius2, wave_min_f32(maxd));
+                const bool keep = mind <= radius2 && mind < inf;
+                const unsigned long long m = __ballot(keep);
+                const uint32_t slot = nn + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                if (keep && slot < (uint32_t)kWaveFrontier) fr[wave][cur ^ 1][slot] = child;
+                nn += (uint32_t)__popcll(m);
+            }
+            if (nn > (uint32_t)kWaveFrontier) { overflowed = true; break; }
+            nf = nn;
+            cur ^= 1;
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (overflowed) {
+            if (lane == 0) overflow[atomicAdd(ov_count, 1u)] = i;
+            continue;
+        }
+        // frontier = leaves: 8 leaves x 8 points per batch
+        for (uint32_t f0 = 0; f0 < nf; f0 += 8) {
+            const uint32_t f = f0 + (uint32_t)(lane >> 3);
+            unsigned long long key = ~0ull;
+            uint32_t j = 0;
+            if (f < nf) {
+                j = fr[wave][cur][f] * kLeaf + (uint32_t)(lane & 7);
+                if (j < ix.n) {
+                    const float4 q = ix.tq[j];
+                    const float d2 = dist2(px, py, pz, q.x, q.y, q.z);
+                    if (d2 == d2) key = ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned long long)(uint32_t)__float_as_int(q.w);
+                }
+            }
+            const unsigned long long best = wave_min_u64(key);
+            if (best < bkey) {
+                bkey = best;
+                const unsigned long long who = __ballot(key == best);
+                bpos = (int32_t)__shfl((int)j, __ffsll((long long)who) - 1, 64);
+            }
+        }
+        if (lane == 0) {
+            a.pos_out[i] = bpos;
+            a.d2_out[i] = (bkey == ~0ull) ? inf : __uint_as_float((uint32_t)(bkey >> 32));
+        }
+    }
+}
+
+__global__ __launch_bounds__(kPassThreads) void k_accumulate(PassArgs a, const float4 *__restrict__ tq, const float4 *__restrict__ tn)
+{
+    Acc acc; acc_zero(acc);
+    const uint32_t nbp = gridDim.x;
+    // grid-stride over blocks of 256 points, XCD-contiguous
+    const uint32_t total_blocks = (a.n + kPassThreads - 1) / kPassThreads;
+    for (uint32_t lb = xcd_remap(blockIdx.x, nbp); lb < total_blocks; lb += nbp) {
+        const uint32_t i = lb * kPassThreads + threadIdx.x;
+        if (i >= a.n) continue;
+        const float x = a.in.x[i], y = a.in.y[i], z = a.in.z[i];
+        const float nx = a.in.nx[i], ny = a.in.ny[i], nz = a.in.nz[i];
+        const int32_t pos = a.pos_out[i];
+        const float d2 = a.d2_out[i];
+        const float px = xf_row(a.X.m + 0, x, y, z, 1.0f), py = xf_row(a.X.m + 4, x, y, z, 1.0f), pz = xf_row(a.X.m + 8, x, y, z, 1.0f);
+        const float npx = xf_row(a.X.m + 0, nx, ny, nz, a.X.nrm_w), npy = xf_row(a.X.m + 4, nx, ny, nz, a.X.nrm_w),
+                    npz = xf_row(a.X.m + 8, nx, ny, nz, a.X.nrm_w);
+        if (a.writeback) {
+            a.out.x[i] = px; a.out.y[i] = py; a.out.z[i] = pz;
+            a.out.nx[i] = npx; a.out.ny[i] = npy; a.out.nz[i] = npz;
+        }
+        if (pos < 0) continue;
+        if (a.max_d2 > 0.0f && d2 > a.max_d2) continue;
+        const float4 q = tq[pos], nq = tn[pos];
+        acc_pair(acc, px, py, pz, npx, npy, npz, q.x, q.y, q.z, nq.x, nq.y, nq.z, d2, a.pivot);
+    }
+    acc_block_reduce_store(acc, a.partials, gridDim.x);
+}
+
+// ---------------------------------------------------------------------------
+// final reduce: partials[40][nblocks] -> 40 doubles.  One 256-thread block per sum: coalesced
+// independent loads, then a fixed pairwise tree in LDS (deterministic).  Writes the device record
+// and, when given, a host-mapped copy (single-GPU read-back without a memcpy).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_final_reduce(const double *__restrict__ partials, int nblocks,
+                                                      double *out_dev, double *out_host)
+{
+    __shared__ double red[256];
+    const int k = blockIdx.x, t = threadIdx.x;
+    const double *row = partials + (size_t)k * nblocks;
+    double s = 0.0;
+    for (int j = t; j < nblocks; j += 256) s += row[j];
+    red[t] = s;
     __syncthreads();
-    if (t < kNSum) {
-        double s = 0.0;
-        for (int strand = 0; strand < kFinalStrands; strand++) s += red[strand * kNSum + t];
-        out_dev[t] = s;
-        if (out_host) out_host[t] = s;
+#pragma unroll
+    for (int off = 128; off > 0; off >>= 1) {
+        if (t < off) red[t] += red[t + off];
+        __syncthreads();
+    }
+    if (t == 0) {
+        out_dev[k] = red[0];
+        if (out_host) out_host[k] = red[0];
     }
 }
 
@@ -516,9 +766,25 @@ void launch_pass_tree(const PassArgs &a, const TargetIndex &ix, int blocks, hipS
     hipLaunchKernelGGL(k_pass_tree, dim3(blocks), dim3(kPassThreads), 0, s, a, ix);
 }
 
+void launch_pass_tree_split(const PassArgs &a, const TargetIndex &ix, uint32_t *worklist, uint32_t *wl_count, int acc_blocks, hipStream_t s)
+{
+    hipMemsetAsync(wl_count, 0, 2 * sizeof(uint32_t), s);      // [0] work list, [1] overflow list
+    const uint32_t nb = (a.n + kPassThreads - 1) / kPassThreads;
+    const uint32_t nbp = ((nb + 7u) / 8u) * 8u;
+    hipLaunchKernelGGL(k_search_fast, dim3(nbp), dim3(kPassThreads), 0, s, a, ix, worklist, wl_count);
+    uint32_t wb = nb < 2048u ? nb : 2048u;
+    if (wb < 1u) wb = 1u;
+    uint32_t *overflow = worklist + a.n, *ov_count = wl_count + 1;
+    hipLaunchKernelGGL(k_search_walk_wave, dim3(2048), dim3(kPassThreads), 0, s, a, ix, (const uint32_t *)worklist,
+                       (const uint32_t *)wl_count, overflow, ov_count);
+    hipLaunchKernelGGL(k_search_walk, dim3(wb), dim3(kPassThreads), 0, s, a, ix, (const uint32_t *)worklist, (const uint32_t *)wl_count,
+                       (const uint32_t *)overflow, (const uint32_t *)ov_count);
+    hipLaunchKernelGGL(k_accumulate, dim3(acc_blocks), dim3(kPassThreads), 0, s, a, ix.tq, ix.tn);
+}
+
 void launch_final_reduce(const double *partials, int blocks, double *out_dev, double *out_host_mapped, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_final_reduce, dim3(1), dim3(1024), 0, s, partials, blocks, out_dev, out_host_mapped);
+    hipLaunchKernelGGL(k_final_reduce, dim3(kNSum), dim3(256), 0, s, partials, blocks, out_dev, out_host_mapped);
 }
 
 void launch_nn_brute(const CloudSoA &src, uint32_t n_s, const Affine &X, const float4 *tq, uint32_t n_t,
