@@ -100,7 +100,7 @@ def main():
     # ---- warmup: W untimed steps ------------------------------------------------------------------
     run(W)
     # ---- timed: begin + exactly K steps, barrier + sync on both sides, max over ranks --------------
-    eng.enable_timing(True)
+    eng.enable_timing(not os.environ.get("SYMMICP_BENCH_NO_EVENTS"))
     best = None
     for _ in range(max(1, args.repeats)):
         eng.reset_stats()

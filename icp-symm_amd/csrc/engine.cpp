@@ -97,7 +97,9 @@ struct symmicp_ctx {
     uint32_t *worklist = nullptr, *wl_count = nullptr;
     // reduction
     int pass_blocks = 0;
-    double *partials = nullptr, *d_sums = nullptr, *h_sums = nullptr, *h_sums_dev = nullptr;
+    double *partials = nullptr, *d_sums = nullptr, *h_sums = nullptr, *h_sums_dev = nullptr;   // h_sums: 40 doubles + sequence word
+    uint32_t *ticket = nullptr;
+    unsigned long long seq = 0;
     // loop state
     bool begun = false;
     int iters = 0;
@@ -117,6 +119,9 @@ struct symmicp_ctx {
             return SYMMICP_ERR_HIP;                                                                         \
         }                                                                                                   \
     } while (0)
+
+static double g_t_launch = 0, g_t_spin = 0, g_t_solve = 0, g_t_between = 0, g_t_last_done = 0;
+static long g_n_pass = 0;
 
 static int fail(symmicp_ctx *c, int code, const std::string &msg)
 {
@@ -194,8 +199,10 @@ int symmicp_create(const symmicp_config *cfg, symmicp_ctx **out)
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return SYMMICP_ERR_HIP; }
     bool ok = hipMalloc((void **)&c->partials, sizeof(double) * kNSum * 8192) == hipSuccess &&
               hipMalloc((void **)&c->d_sums, sizeof(double) * kNSum) == hipSuccess &&
-              hipHostMalloc((void **)&c->h_sums, sizeof(double) * kNSum, hipHostMallocMapped) == hipSuccess &&
+              hipHostMalloc((void **)&c->h_sums, sizeof(double) * (kNSum + 8), hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess &&
+              hipMalloc((void **)&c->ticket, sizeof(uint32_t)) == hipSuccess && hipMemset(c->ticket, 0, sizeof(uint32_t)) == hipSuccess &&
               hipHostGetDevicePointer((void **)&c->h_sums_dev, c->h_sums, 0) == hipSuccess &&
+              std::memset(c->h_sums, 0, sizeof(double) * (kNSum + 8)) != nullptr &&
               hipEventCreate(&c->ev0) == hipSuccess && hipEventCreate(&c->ev1) == hipSuccess;
     if (!ok) { symmicp_destroy(c); return SYMMICP_ERR_HIP; }
     identity16(c->X);
@@ -221,12 +228,14 @@ static void free_source(symmicp_ctx *c)
 void symmicp_destroy(symmicp_ctx *c)
 {
     if (!c) return;
+    if (std::getenv("SYMMICP_DEBUG_HOST") && g_n_pass)
+        std::fprintf(stderr, "[symmicp host] passes %ld: launch %.1f us, spin %.1f us, between passes %.1f us (per pass)\n", g_n_pass, 1e6 * g_t_launch / g_n_pass, 1e6 * g_t_spin / g_n_pass, 1e6 * g_t_between / g_n_pass);
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
     if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
     free_target(c);
     free_source(c);
-    hipFree(c->partials); hipFree(c->d_sums);
+    hipFree(c->partials); hipFree(c->d_sums); hipFree(c->ticket);
     if (c->h_sums) hipHostFree(c->h_sums);
     if (c->ev0) hipEventDestroy(c->ev0);
     if (c->ev1) hipEventDestroy(c->ev1);
@@ -494,6 +503,7 @@ int symmicp_set_source(symmicp_ctx *c, const float *xyz, size_t xr, size_t xc, c
     if (c->cfg.corr == SYMMICP_CORR_TREE) {
         HIP_TRY(c, hipMalloc((void **)&c->worklist, sizeof(uint32_t) * 2 * nl));      // work list + overflow list
         HIP_TRY(c, hipMalloc((void **)&c->wl_count, 2 * sizeof(uint32_t)));
+        HIP_TRY(c, hipMemset(c->wl_count, 0, 2 * sizeof(uint32_t)));
     }
     HIP_TRY(c, hipGetLastError());
     c->st.upload_ms += (now_s() - t0) * 1e3;
@@ -526,6 +536,8 @@ static int run_pass(symmicp_ctx *c, const float Xapply[16], bool from_cur, bool 
     if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
     c->pass_blocks = blocks;
+    const double t_l0 = now_s();
+    if (g_t_last_done > 0) g_t_between += t_l0 - g_t_last_done;
     if (c->timing) hipEventRecord(c->ev0, c->stream);
     switch (c->cfg.corr) {
     case SYMMICP_CORR_IDENTITY:
@@ -540,21 +552,45 @@ static int run_pass(symmicp_ctx *c, const float Xapply[16], bool from_cur, bool 
             launch_pass_tree(a, c->ix, blocks, c->stream);
         } else {
             // the accumulate kernel is streaming: 8 blocks per CU worth of grid, a multiple of 8 for the XCD remap
-            int ab = blocks < 2048 ? ((blocks + 7) / 8) * 8 : 2048;
+            static const int acc_cap = std::getenv("SYMMICP_ACC_BLOCKS") ? std::atoi(std::getenv("SYMMICP_ACC_BLOCKS")) : 2048;
+            const int nb_all = (int)((c->n_loc + kPassThreads - 1) / kPassThreads);
+            int ab = nb_all < acc_cap ? ((nb_all + 7) / 8) * 8 : acc_cap;
             c->pass_blocks = blocks = ab;
             launch_pass_tree_split(a, c->ix, c->worklist, c->wl_count, ab, c->stream);
         }
         break;
     }
     if (c->timing) hipEventRecord(c->ev1, c->stream);
-    launch_final_reduce(c->partials, blocks, c->d_sums, c->comm ? nullptr : c->h_sums_dev, c->stream);
+    const unsigned long long seq = ++c->seq;
+    volatile unsigned long long *flag = reinterpret_cast<volatile unsigned long long *>(c->h_sums + kNSum);
+    launch_final_reduce(c->partials, blocks, c->d_sums, c->comm ? nullptr : c->h_sums_dev, c->ticket, seq, c->wl_count, c->stream);
     if (c->comm) {
         int r = g_rccl.AllReduce(c->d_sums, c->d_sums, kNSum, kNcclFloat64, kNcclSum, c->comm, c->stream);
         if (r != 0) return fail(c, SYMMICP_ERR_COMM, std::string("ncclAllReduce: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?"));
-        HIP_TRY(c, hipMemcpyAsync(c->h_sums, c->d_sums, sizeof(double) * kNSum, hipMemcpyDeviceToHost, c->stream));
+        launch_publish(c->d_sums, c->h_sums_dev, seq, c->stream);
     }
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    HIP_TRY(c, hipGetLastError());
+    // The record arrives in host-mapped memory followed by its sequence number: spin on that word instead of
+    // paying a stream-synchronise wake-up per iteration.  A stuck stream (kernel fault) is caught by the fallback.
+    g_t_launch += now_s() - t_l0;
+    {
+        const double t_spin = now_s();
+        unsigned spins = 0;
+        bool got = false;
+        while (!(got = (*flag == seq))) {
+            __builtin_ia32_pause();
+            if ((++spins & 0xFFFu) == 0) {
+                if (hipStreamQuery(c->stream) != hipErrorNotReady) { got = (*flag == seq); break; }
+                if (now_s() - t_spin > 30.0) break;
+            }
+        }
+        __atomic_thread_fence(__ATOMIC_ACQUIRE);
+        g_t_spin += now_s() - t_spin; g_t_last_done = now_s(); g_n_pass++;
+        if (!got) {
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            HIP_TRY(c, hipGetLastError());
+            if (*flag != seq) return fail(c, SYMMICP_ERR_HIP, "pass finished without publishing its record");
+        }
+    }
     if (c->ix.dbg) {
         unsigned long long h[8];
         hipMemcpy(h, c->ix.dbg, sizeof(h), hipMemcpyDeviceToHost);
@@ -564,6 +600,7 @@ static int run_pass(symmicp_ctx *c, const float Xapply[16], bool from_cur, bool 
     std::memcpy(c->last.s, c->h_sums, sizeof(double) * kNSum);
     if (c->timing) {
         float ms = 0.f;
+        hipEventSynchronize(c->ev1);
         if (hipEventElapsedTime(&ms, c->ev0, c->ev1) == hipSuccess) { c->st.last_pass_ms = ms; c->st.sum_pass_ms += ms; }
     }
     c->st.passes++;

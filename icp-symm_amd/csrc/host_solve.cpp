@@ -28,10 +28,12 @@ struct SymSolver {
         double B[N][N];
         std::memcpy(B, A, sizeof(B));
         for (int sweep = 0; sweep < 30; ++sweep) {
-            double off = 0.0;
-            for (int i = 0; i < N; ++i)
+            double off = 0.0, diag = 0.0;
+            for (int i = 0; i < N; ++i) {
+                diag += B[i][i] * B[i][i];
                 for (int j = i + 1; j < N; ++j) off += B[i][j] * B[i][j];
-            if (off == 0.0) break;
+            }
+            if (off <= 1e-30 * diag) break;      // converged far below fp64 resolution of the eigenvalues
             for (int p = 0; p < N - 1; ++p)
                 for (int q = p + 1; q < N; ++q) {
                     if (B[p][q] == 0.0) continue;

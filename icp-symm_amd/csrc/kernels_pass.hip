@@ -13,6 +13,7 @@
 // fp32 expressions here must stay UNFUSED (compiled with -ffp-contract=off) and
 // keep the association written: the CPU oracle uses the same expressions, so
 // nearest-neighbour choices compare bit for bit.
+#include <cstdlib>
 #include "symmicp_internal.h"
 #pragma clang fp contract(off)
 
@@ -84,7 +85,29 @@ __device__ __forceinline__ void acc_pair(Acc &a, float px, float py, float pz, f
     a.v[36] += (double)d2;
 }
 
-// block reduction: wave64 shuffle tree, then LDS across waves; fixed order -> deterministic
+// wave64 sum on the VALU's DPP cross-lane network (no LDS traffic): row_shr 1,2,4,8 builds 16-lane row
+// sums, row_bcast15 / row_bcast31 carry them across rows; the total ends up in lane 63.  A double moves as
+// two 32-bit DPP movs; lanes without a source read 0 (bound_ctrl), i.e. add +0.0.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_add_f64(double x)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, ROW_MASK, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, ROW_MASK, 0xf, true);
+    return x + __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ double wave_sum_to_lane63(double x)
+{
+    x = dpp_add_f64<0x111, 0xf>(x);      // row_shr:1
+    x = dpp_add_f64<0x112, 0xf>(x);      // row_shr:2
+    x = dpp_add_f64<0x114, 0xf>(x);      // row_shr:4
+    x = dpp_add_f64<0x118, 0xf>(x);      // row_shr:8  -> lane 15 of each row holds the row sum
+    x = dpp_add_f64<0x142, 0xa>(x);      // row_bcast15 into rows 1 and 3
+    x = dpp_add_f64<0x143, 0xc>(x);      // row_bcast31 into rows 2 and 3 -> lane 63 holds the wave sum
+    return x;
+}
+
+// block reduction: DPP wave sums, then LDS across the 4 waves; fixed order -> deterministic.
 // record k of block b lands at partials[k * nblocks + b] (transposed: the final reduce reads it coalesced)
 __device__ __forceinline__ void acc_block_reduce_store(Acc &a, double *partials, uint32_t nblocks)
 {
@@ -92,10 +115,8 @@ __device__ __forceinline__ void acc_block_reduce_store(Acc &a, double *partials,
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
     for (int k = 0; k < kNAcc; k++) {
-        double x = a.v[k];
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
-        if (lane == 0) red[wave * kNSum + k] = x;
+        const double x = wave_sum_to_lane63(a.v[k]);
+        if (lane == 63) red[wave * kNSum + k] = x;
     }
     __syncthreads();
     if (threadIdx.x < kNSum) {
@@ -427,7 +448,6 @@ __global__ __launch_bounds__(kPassThreads) void k_pass_tree(PassArgs a, TargetIn
 // sorted source per XCD: each XCD's 4 MB L2 then serves one compact region of the target.
 // ---------------------------------------------------------------------------
 constexpr int kWaveFrontier = 512;        // nodes per level per wave (k_search_walk_wave)
-constexpr uint32_t kWaveModeMax = 65536;  // work lists longer than this use one thread per query
 
 __device__ __forceinline__ uint32_t xcd_remap(uint32_t b, uint32_t nb_padded)
 {
@@ -486,7 +506,7 @@ __global__ __launch_bounds__(kPassThreads) void k_search_fast(PassArgs a, Target
 // the overflow list of k_search_walk_wave is left.
 __global__ __launch_bounds__(kPassThreads) void k_search_walk(PassArgs a, TargetIndex ix, const uint32_t *__restrict__ worklist,
                                                              const uint32_t *__restrict__ wl_count, const uint32_t *__restrict__ overflow,
-                                                             const uint32_t *__restrict__ ov_count)
+                                                             const uint32_t *__restrict__ ov_count, uint32_t kWaveModeMax)
 {
     uint32_t count = *wl_count;
     if (count <= kWaveModeMax) { worklist = overflow; count = *ov_count; }
@@ -543,7 +563,7 @@ __device__ __forceinline__ float wave_min_f32(float v)
 
 __global__ __launch_bounds__(kPassThreads) void k_search_walk_wave(PassArgs a, TargetIndex ix, const uint32_t *__restrict__ worklist,
                                                                   const uint32_t *__restrict__ wl_count, uint32_t *overflow,
-                                                                  uint32_t *ov_count)
+                                                                  uint32_t *ov_count, uint32_t kWaveModeMax)
 {
     __shared__ uint32_t fr[kPassThreads / 64][2][kWaveFrontier];
     const uint32_t count = *wl_count;
@@ -670,7 +690,8 @@ __global__ __launch_bounds__(kPassThreads) void k_accumulate(PassArgs a, const f
 // and, when given, a host-mapped copy (single-GPU read-back without a memcpy).
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_final_reduce(const double *__restrict__ partials, int nblocks,
-                                                      double *out_dev, double *out_host)
+                                                      double *out_dev, double *out_host, uint32_t *ticket,
+                                                      unsigned long long seq, uint32_t *counters_to_clear)
 {
     __shared__ double red[256];
     const int k = blockIdx.x, t = threadIdx.x;
@@ -687,6 +708,28 @@ __global__ __launch_bounds__(256) void k_final_reduce(const double *__restrict__
     if (t == 0) {
         out_dev[k] = red[0];
         if (out_host) out_host[k] = red[0];
+        // the block that takes the last ticket publishes the sequence number the host spins on
+        __threadfence_system();
+        if (atomicAdd(ticket, 1u) == gridDim.x - 1) {
+            *ticket = 0;
+            if (counters_to_clear) { counters_to_clear[0] = 0; counters_to_clear[1] = 0; }
+            if (out_host) {
+                __threadfence_system();
+                reinterpret_cast<volatile unsigned long long *>(out_host)[kNSum] = seq;
+            }
+        }
+    }
+}
+
+// multi-GPU: after the RCCL all-reduce, copy the record to host-mapped memory and publish the sequence number
+__global__ __launch_bounds__(64) void k_publish(const double *__restrict__ sums_dev, double *out_host, unsigned long long seq)
+{
+    if (threadIdx.x < kNSum) out_host[threadIdx.x] = sums_dev[threadIdx.x];
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence_system();
+        reinterpret_cast<volatile unsigned long long *>(out_host)[kNSum] = seq;
     }
 }
 
@@ -768,7 +811,8 @@ void launch_pass_tree(const PassArgs &a, const TargetIndex &ix, int blocks, hipS
 
 void launch_pass_tree_split(const PassArgs &a, const TargetIndex &ix, uint32_t *worklist, uint32_t *wl_count, int acc_blocks, hipStream_t s)
 {
-    hipMemsetAsync(wl_count, 0, 2 * sizeof(uint32_t), s);      // [0] work list, [1] overflow list
+    static const uint32_t wave_mode_max = getenv("SYMMICP_WAVE_MODE_MAX") ? (uint32_t)atol(getenv("SYMMICP_WAVE_MODE_MAX")) : 65536u;   // work lists longer than this use one thread per query
+    // wl_count[0] (work list) and [1] (overflow list) are zero here: cleared by the previous pass's final reduce
     const uint32_t nb = (a.n + kPassThreads - 1) / kPassThreads;
     const uint32_t nbp = ((nb + 7u) / 8u) * 8u;
     hipLaunchKernelGGL(k_search_fast, dim3(nbp), dim3(kPassThreads), 0, s, a, ix, worklist, wl_count);
@@ -776,15 +820,22 @@ void launch_pass_tree_split(const PassArgs &a, const TargetIndex &ix, uint32_t *
     if (wb < 1u) wb = 1u;
     uint32_t *overflow = worklist + a.n, *ov_count = wl_count + 1;
     hipLaunchKernelGGL(k_search_walk_wave, dim3(2048), dim3(kPassThreads), 0, s, a, ix, (const uint32_t *)worklist,
-                       (const uint32_t *)wl_count, overflow, ov_count);
+                       (const uint32_t *)wl_count, overflow, ov_count, wave_mode_max);
     hipLaunchKernelGGL(k_search_walk, dim3(wb), dim3(kPassThreads), 0, s, a, ix, (const uint32_t *)worklist, (const uint32_t *)wl_count,
-                       (const uint32_t *)overflow, (const uint32_t *)ov_count);
+                       (const uint32_t *)overflow, (const uint32_t *)ov_count, wave_mode_max);
     hipLaunchKernelGGL(k_accumulate, dim3(acc_blocks), dim3(kPassThreads), 0, s, a, ix.tq, ix.tn);
 }
 
-void launch_final_reduce(const double *partials, int blocks, double *out_dev, double *out_host_mapped, hipStream_t s)
+void launch_final_reduce(const double *partials, int blocks, double *out_dev, double *out_host_mapped, uint32_t *ticket,
+                         unsigned long long seq, uint32_t *counters_to_clear, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_final_reduce, dim3(kNSum), dim3(256), 0, s, partials, blocks, out_dev, out_host_mapped);
+    hipLaunchKernelGGL(k_final_reduce, dim3(kNSum), dim3(256), 0, s, partials, blocks, out_dev, out_host_mapped, ticket, seq,
+                       counters_to_clear);
+}
+
+void launch_publish(const double *sums_dev, double *out_host_mapped, unsigned long long seq, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, s, sums_dev, out_host_mapped, seq);
 }
 
 void launch_nn_brute(const CloudSoA &src, uint32_t n_s, const Affine &X, const float4 *tq, uint32_t n_t,

@@ -75,7 +75,9 @@ void launch_pass_identity(const PassArgs &a, CloudSoA tgt, int blocks, hipStream
 void launch_pass_indexed(const PassArgs &a, const float4 *tq, const float4 *tn, int blocks, hipStream_t s);
 void launch_pass_tree(const PassArgs &a, const TargetIndex &ix, int blocks, hipStream_t s);
 void launch_pass_tree_split(const PassArgs &a, const TargetIndex &ix, uint32_t *worklist, uint32_t *wl_count, int acc_blocks, hipStream_t s);
-void launch_final_reduce(const double *partials, int blocks, double *out_dev, double *out_host_mapped, hipStream_t s);
+void launch_final_reduce(const double *partials, int blocks, double *out_dev, double *out_host_mapped, uint32_t *ticket,
+                         unsigned long long seq, uint32_t *counters_to_clear, hipStream_t s);
+void launch_publish(const double *sums_dev, double *out_host_mapped, unsigned long long seq, hipStream_t s);
 void launch_nn_brute(const CloudSoA &src, uint32_t n_s, const Affine &X, const float4 *tq, uint32_t n_t,
                      unsigned long long *best64, hipStream_t s);
 
