@@ -94,7 +94,8 @@ struct symmicp_ctx {
     int32_t *pos = nullptr;
     float *d2 = nullptr;
     unsigned long long *best64 = nullptr;
-    uint32_t *worklist = nullptr, *wl_count = nullptr;
+    uint32_t *worklist = nullptr, *wl_count = nullptr;   // 3 sharded lists + their counters
+    WorkLists wl{};
     // reduction
     int pass_blocks = 0;
     double *partials = nullptr, *d_sums = nullptr, *h_sums = nullptr, *h_sums_dev = nullptr;   // h_sums: 40 doubles + sequence word
@@ -501,9 +502,15 @@ int symmicp_set_source(symmicp_ctx *c, const float *xyz, size_t xr, size_t xc, c
     HIP_TRY(c, hipMalloc((void **)&c->d2, sizeof(float) * nl));
     if (c->cfg.corr == SYMMICP_CORR_BRUTE) HIP_TRY(c, hipMalloc((void **)&c->best64, sizeof(unsigned long long) * nl));
     if (c->cfg.corr == SYMMICP_CORR_TREE) {
-        HIP_TRY(c, hipMalloc((void **)&c->worklist, sizeof(uint32_t) * 2 * nl));      // work list + overflow list
-        HIP_TRY(c, hipMalloc((void **)&c->wl_count, 2 * sizeof(uint32_t)));
-        HIP_TRY(c, hipMemset(c->wl_count, 0, 2 * sizeof(uint32_t)));
+        const uint32_t cap = shard_capacity(nl);
+        const size_t per_list = (size_t)kShards * cap, ncount = (size_t)kShards * kShardStride;
+        HIP_TRY(c, hipMalloc((void **)&c->worklist, sizeof(uint32_t) * 3 * per_list));      // work, overflow, medium
+        HIP_TRY(c, hipMalloc((void **)&c->wl_count, sizeof(uint32_t) * 3 * ncount));
+        HIP_TRY(c, hipMemset(c->wl_count, 0, sizeof(uint32_t) * 3 * ncount));
+        c->wl.work = ShardList{c->worklist, c->wl_count, cap};
+        c->wl.overflow = ShardList{c->worklist + per_list, c->wl_count + ncount, cap};
+        c->wl.medium = ShardList{c->worklist + 2 * per_list, c->wl_count + 2 * ncount, cap};
+        c->wl.all_counts = c->wl_count;
     }
     HIP_TRY(c, hipGetLastError());
     c->st.upload_ms += (now_s() - t0) * 1e3;
@@ -556,7 +563,7 @@ static int run_pass(symmicp_ctx *c, const float Xapply[16], bool from_cur, bool 
             const int nb_all = (int)((c->n_loc + kPassThreads - 1) / kPassThreads);
             int ab = nb_all < acc_cap ? ((nb_all + 7) / 8) * 8 : acc_cap;
             c->pass_blocks = blocks = ab;
-            launch_pass_tree_split(a, c->ix, c->worklist, c->wl_count, ab, c->stream);
+            launch_pass_tree_split(a, c->ix, c->wl, ab, c->stream);
         }
         break;
     }

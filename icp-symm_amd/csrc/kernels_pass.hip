@@ -449,78 +449,234 @@ __global__ __launch_bounds__(kPassThreads) void k_pass_tree(PassArgs a, TargetIn
 // ---------------------------------------------------------------------------
 constexpr int kWaveFrontier = 512;        // nodes per level per wave (k_search_walk_wave)
 
+__device__ __forceinline__ void sl_push(const ShardList &L, uint32_t shard, uint32_t v)
+{
+    const uint32_t k = atomicAdd(L.counts + shard * kShardStride, 1u);
+    L.items[(size_t)shard * L.cap + k] = v;
+}
+
+// A list is consumed as the concatenation of its shards (balances consumers when shards are unevenly filled).
+// sl_prefix: every thread of the block calls it once; pre[0..64] = exclusive prefix sums of the shard counts.
+__device__ __forceinline__ void sl_prefix(const ShardList &L, uint32_t *pre /* __shared__ [kShards + 1] */)
+{
+    if (threadIdx.x < kShards) {
+        uint32_t v = L.counts[threadIdx.x * kShardStride];
+#pragma unroll
+        for (int off = 1; off < kShards; off <<= 1) {
+            const uint32_t u = __shfl_up(v, off, 64);
+            if ((int)threadIdx.x >= off) v += u;
+        }
+        pre[threadIdx.x + 1] = v;
+        if (threadIdx.x == 0) pre[0] = 0;
+    }
+    __syncthreads();
+}
+
+// entry number g of the concatenated list; false when g is past the end
+__device__ __forceinline__ bool sl_locate(const ShardList &L, const uint32_t *pre, uint32_t g, uint32_t &item)
+{
+    if (g >= pre[kShards]) return false;
+    int lo = 0;
+#pragma unroll
+    for (int step = kShards / 2; step > 0; step >>= 1)
+        if (pre[lo + step] <= g) lo += step;
+    item = L.items[(size_t)lo * L.cap + (g - pre[lo])];
+    return true;
+}
+
+__device__ __forceinline__ uint32_t sl_total(const ShardList &L)
+{
+    uint32_t t = 0;
+    for (int sh = 0; sh < kShards; sh++) t += L.counts[sh * kShardStride];
+    return t;
+}
+
 __device__ __forceinline__ uint32_t xcd_remap(uint32_t b, uint32_t nb_padded)
 {
     return (b & 7u) * (nb_padded >> 3) + (b >> 3);
 }
 
-__global__ __launch_bounds__(kPassThreads) void k_search_fast(PassArgs a, TargetIndex ix, uint32_t *worklist, uint32_t *wl_count)
+// squared gap (minus the safety margin) between the query coordinate and the cell [lo, lo+h) on one axis
+__device__ __forceinline__ float axis_gap2(float p, float origin, int c, float h, float margin)
 {
-    const uint32_t i = xcd_remap(blockIdx.x, gridDim.x) * kPassThreads + threadIdx.x;
-    if (i >= a.n) return;
-    const float x = a.in.x[i], y = a.in.y[i], z = a.in.z[i];
-    const int32_t prev = a.pos_prev ? a.pos_prev[i] : -1;
-    const float px = xf_row(a.X.m + 0, x, y, z, 1.0f), py = xf_row(a.X.m + 4, x, y, z, 1.0f), pz = xf_row(a.X.m + 8, x, y, z, 1.0f);
+    const float lo = origin + (float)c * h;
+    const float g = fmaxf(fmaxf(lo - p, p - (lo + h)) - margin, 0.0f);
+    return g * g;
+}
+
+// ---------------------------------------------------------------------------
+// k_search_cells: the common case of a pass, load-balanced at (query, cell) granularity.
+//   phase 1  thread = query: transform, previous-pair bound, the <= 3x3x3 cells its ball overlaps, and which of
+//            them can still hold something not farther than the bound.  Each surviving (query, cell) pair becomes
+//            a 13-bit work item in LDS (block-wide prefix sum gives the slots).  Queries without a previous pair or
+//            with a wider ball go to the work list of the tree-walk kernels.
+//   phase 2  thread = work item: one cell range, its points four at a time, result merged per query with an LDS
+//            64-bit atomicMin on (d2 bits << 32 | row)  -- min is order independent, ties resolve to the lowest row.
+//   phase 3  thread = query: store the pair.
+// A wave's cost is now the largest single CELL in it, not the largest sum over a query's cells, and queries with 27
+// cells no longer drag their whole wave through 27 steps.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(kPassThreads) void k_search_cells(PassArgs a, TargetIndex ix, WorkLists wl)
+{
+    __shared__ float s_px[kPassThreads], s_py[kPassThreads], s_pz[kPassThreads];
+    __shared__ unsigned long long s_key[kPassThreads];
+    __shared__ int32_t s_pos[kPassThreads];
+    __shared__ uint32_t s_cell0[kPassThreads];
+    __shared__ uint16_t s_items[kPassThreads * 27];
+    __shared__ uint32_t s_wsum[kPassThreads / 64 + 1];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t shard = blockIdx.x & (kShards - 1);
+    const uint32_t i = xcd_remap(blockIdx.x, gridDim.x) * kPassThreads + tid;
+    const bool active = i < a.n;
+
+    // ---- phase 1 ----
+    float px = 0.f, py = 0.f, pz = 0.f;
     Best b;
     b.d2 = __int_as_float(0x7f800000); b.pos = -1; b.row = 0x7fffffff;
-    if (prev >= 0 && (uint32_t)prev < ix.n) test_point(b, ix.tq[prev], prev, px, py, pz);
-    bool done = false;
-    if (b.pos >= 0 && ix.glevel > 0) {
-        const float margin = 2e-3f * ix.h;
-        const float gmax = (float)ix.gdim;
-        const float r = sqrtf(b.d2) * 1.000001f + margin;
-        const float lx = (px - r - ix.ox) * ix.inv_h, hx = (px + r - ix.ox) * ix.inv_h;
-        const float ly = (py - r - ix.oy) * ix.inv_h, hy = (py + r - ix.oy) * ix.inv_h;
-        const float lz = (pz - r - ix.oz) * ix.inv_h, hz = (pz + r - ix.oz) * ix.inv_h;
-        const int x0 = (int)floorf(fminf(fmaxf(lx, 0.0f), gmax - 1.0f)), x1 = (int)floorf(fminf(fmaxf(hx, 0.0f), gmax - 1.0f));
-        const int y0 = (int)floorf(fminf(fmaxf(ly, 0.0f), gmax - 1.0f)), y1 = (int)floorf(fminf(fmaxf(hy, 0.0f), gmax - 1.0f));
-        const int z0 = (int)floorf(fminf(fmaxf(lz, 0.0f), gmax - 1.0f)), z1 = (int)floorf(fminf(fmaxf(hz, 0.0f), gmax - 1.0f));
-        if (x1 - x0 <= 2 && y1 - y0 <= 2 && z1 - z0 <= 2) {
-            for (int zz = z0; zz <= z1; zz++) {
-                const float zlo = ix.oz + (float)zz * ix.h;
-                const float gz = fmaxf(fmaxf(zlo - pz, pz - (zlo + ix.h)) - margin, 0.0f);
-                const uint32_t mz = spread3((uint32_t)zz) << 2;
-                for (int yy = y0; yy <= y1; yy++) {
-                    const float ylo = ix.oy + (float)yy * ix.h;
-                    const float gy = fmaxf(fmaxf(ylo - py, py - (ylo + ix.h)) - margin, 0.0f);
-                    const uint32_t mzy = mz | (spread3((uint32_t)yy) << 1);
-                    for (int xx = x0; xx <= x1; xx++) {
-                        const float xlo = ix.ox + (float)xx * ix.h;
-                        const float gx = fmaxf(fmaxf(xlo - px, px - (xlo + ix.h)) - margin, 0.0f);
-                        const float g2 = (gx * gx + gy * gy) + gz * gz;
-                        if (g2 > b.d2) continue;
-                        const uint2 rng = ix.cells[mzy | spread3((uint32_t)xx)];
-                        for (uint32_t j = rng.x; j < rng.y; j++) test_point(b, ix.tq[j], (int32_t)j, px, py, pz);
-                    }
+    uint32_t mask = 0;                 // surviving cells of this query, bit = kx + 3*ky + 9*kz
+    bool defer = false;
+    if (active) {
+        const float x = a.in.x[i], y = a.in.y[i], z = a.in.z[i];
+        const int32_t prev = a.pos_prev ? a.pos_prev[i] : -1;
+        px = xf_row(a.X.m + 0, x, y, z, 1.0f); py = xf_row(a.X.m + 4, x, y, z, 1.0f); pz = xf_row(a.X.m + 8, x, y, z, 1.0f);
+        if (prev >= 0 && (uint32_t)prev < ix.n) test_point(b, ix.tq[prev], prev, px, py, pz);
+        defer = true;
+        if (b.pos >= 0 && ix.glevel > 0) {
+            const float margin = 2e-3f * ix.h;
+            const float gmax = (float)ix.gdim;
+            // any r >= sqrt(d2) is valid here: the hardware square root (1 ulp) with a relative pad
+            const float r = __builtin_amdgcn_sqrtf(b.d2) * 1.00001f + margin;
+            const float lx = (px - r - ix.ox) * ix.inv_h, hx = (px + r - ix.ox) * ix.inv_h;
+            const float ly = (py - r - ix.oy) * ix.inv_h, hy = (py + r - ix.oy) * ix.inv_h;
+            const float lz = (pz - r - ix.oz) * ix.inv_h, hz = (pz + r - ix.oz) * ix.inv_h;
+            const int x0 = (int)floorf(fminf(fmaxf(lx, 0.0f), gmax - 1.0f)), x1 = (int)floorf(fminf(fmaxf(hx, 0.0f), gmax - 1.0f));
+            const int y0 = (int)floorf(fminf(fmaxf(ly, 0.0f), gmax - 1.0f)), y1 = (int)floorf(fminf(fmaxf(hy, 0.0f), gmax - 1.0f));
+            const int z0 = (int)floorf(fminf(fmaxf(lz, 0.0f), gmax - 1.0f)), z1 = (int)floorf(fminf(fmaxf(hz, 0.0f), gmax - 1.0f));
+            const int nx = x1 - x0, ny = y1 - y0, nz = z1 - z0;      // extra cells per axis
+            if (nx <= 2 && ny <= 2 && nz <= 2) {
+                defer = false;
+                const float inf = __int_as_float(0x7f800000);
+                float gx[3], gy[3], gz[3];
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                    gx[k] = (k <= nx) ? axis_gap2(px, ix.ox, x0 + k, ix.h, margin) : inf;
+                    gy[k] = (k <= ny) ? axis_gap2(py, ix.oy, y0 + k, ix.h, margin) : inf;
+                    gz[k] = (k <= nz) ? axis_gap2(pz, ix.oz, z0 + k, ix.h, margin) : inf;
                 }
+#pragma unroll
+                for (int kz = 0; kz < 3; kz++)
+#pragma unroll
+                    for (int ky = 0; ky < 3; ky++)
+#pragma unroll
+                        for (int kx = 0; kx < 3; kx++) {
+                            const float g2 = (gx[kx] + gy[ky]) + gz[kz];
+                            if (g2 <= b.d2) mask |= 1u << (kx + 3 * ky + 9 * kz);
+                        }
+                s_cell0[tid] = (uint32_t)x0 | ((uint32_t)y0 << 10) | ((uint32_t)z0 << 20);
             }
-            done = true;
+        }
+        if (defer) {
+            a.pos_out[i] = b.pos;        // provisional: the tree walk starts from this bound
+            a.d2_out[i] = b.d2;
+            sl_push(wl.work, shard, i);
         }
     }
-    a.pos_out[i] = b.pos;            // provisional for work-list entries: the walk starts from this bound
-    a.d2_out[i] = b.d2;
-    if (!done) worklist[atomicAdd(wl_count, 1u)] = i;
+    s_px[tid] = px; s_py[tid] = py; s_pz[tid] = pz;
+    s_pos[tid] = b.pos;
+    s_key[tid] = (b.pos >= 0) ? (((unsigned long long)__float_as_uint(b.d2) << 32) | (unsigned long long)(uint32_t)b.row) : ~0ull;
+    // block-wide exclusive prefix sum of the item counts
+    const uint32_t cnt = (uint32_t)__popc(mask);
+    uint32_t incl = cnt;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t u = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += u;
+    }
+    if (lane == 63) s_wsum[wave] = incl;
+    __syncthreads();
+    uint32_t base = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < kPassThreads / 64; w++) {
+        const uint32_t ws = s_wsum[w];
+        if (w < wave) base += ws;
+        total += ws;
+    }
+    {
+        uint32_t slot = base + incl - cnt;
+        uint32_t m = mask;
+        while (m) {
+            const int bit = __ffs((int)m) - 1;
+            m &= m - 1;
+            s_items[slot++] = (uint16_t)((tid << 5) | bit);
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 2 ----
+    for (uint32_t it0 = 0; it0 < total; it0 += kPassThreads) {
+        const uint32_t it = it0 + tid;
+        unsigned long long mykey = ~0ull;
+        int32_t mypos = -1;
+        int q = 0;
+        if (it < total) {
+            const uint32_t item = s_items[it];
+            q = (int)(item >> 5);
+            const int bit = (int)(item & 31u);
+            const int kz = bit / 9, ky = (bit - 9 * kz) / 3, kx = bit - 9 * kz - 3 * ky;
+            const uint32_t c0 = s_cell0[q];
+            const uint32_t cx = (c0 & 1023u) + (uint32_t)kx, cy = ((c0 >> 10) & 1023u) + (uint32_t)ky, cz = (c0 >> 20) + (uint32_t)kz;
+            const uint2 rng = ix.cells[(spread3(cz) << 2) | (spread3(cy) << 1) | spread3(cx)];
+            const float qx = s_px[q], qy = s_py[q], qz = s_pz[q];
+            Best lb;
+            lb.d2 = __int_as_float(0x7f800000); lb.pos = -1; lb.row = 0x7fffffff;
+            for (uint32_t j = rng.x; j < rng.y; j += 4) {
+                float4 t4[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) t4[k] = ix.tq[min(j + (uint32_t)k, rng.y - 1)];
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                    if (j + (uint32_t)k < rng.y) test_point(lb, t4[k], (int32_t)(j + k), qx, qy, qz);
+            }
+            if (lb.pos >= 0) {
+                mykey = ((unsigned long long)__float_as_uint(lb.d2) << 32) | (unsigned long long)(uint32_t)lb.row;
+                mypos = lb.pos;
+                atomicMin(&s_key[q], mykey);
+            }
+        }
+        __syncthreads();
+        if (mypos >= 0 && s_key[q] == mykey) s_pos[q] = mypos;
+    }
+    __syncthreads();
+
+    // ---- phase 3 ----
+    if (active && !defer) {
+        const unsigned long long key = s_key[tid];
+        a.pos_out[i] = s_pos[tid];
+        a.d2_out[i] = __uint_as_float((uint32_t)(key >> 32));
+    }
 }
 
 // one thread per query.  Long work lists (far passes) come here directly; for short lists (wave mode) only
 // the overflow list of k_search_walk_wave is left.
-__global__ __launch_bounds__(kPassThreads) void k_search_walk(PassArgs a, TargetIndex ix, const uint32_t *__restrict__ worklist,
-                                                             const uint32_t *__restrict__ wl_count, const uint32_t *__restrict__ overflow,
-                                                             const uint32_t *__restrict__ ov_count, uint32_t kWaveModeMax)
+__global__ __launch_bounds__(kPassThreads) void k_search_walk(PassArgs a, TargetIndex ix, WorkLists wl, uint32_t kWaveModeMax)
 {
-    uint32_t count = *wl_count;
-    if (count <= kWaveModeMax) { worklist = overflow; count = *ov_count; }
-    for (uint32_t w = blockIdx.x * blockDim.x + threadIdx.x; w < count; w += gridDim.x * blockDim.x) {
-        const uint32_t i = worklist[w];
-        const float x = a.in.x[i], y = a.in.y[i], z = a.in.z[i];
-        const float px = xf_row(a.X.m + 0, x, y, z, 1.0f), py = xf_row(a.X.m + 4, x, y, z, 1.0f), pz = xf_row(a.X.m + 8, x, y, z, 1.0f);
-        Best b;
-        b.pos = a.pos_out[i]; b.d2 = a.d2_out[i]; b.row = 0x7fffffff;
-        if (b.pos >= 0) b.row = __float_as_int(ix.tq[b.pos].w);
-        tree_walk_nf(ix, px, py, pz, b);
-        a.pos_out[i] = b.pos;
-        a.d2_out[i] = b.d2;
-    }
+    __shared__ uint32_t pre[kShards + 1];
+    sl_prefix(wl.work, pre);
+    const bool wave_mode = pre[kShards] <= kWaveModeMax;      // then only the overflow list is left for this kernel
+    __syncthreads();
+    if (wave_mode) sl_prefix(wl.overflow, pre);
+    const ShardList &L = wave_mode ? wl.overflow : wl.work;
+    uint32_t i;
+    if (!sl_locate(L, pre, blockIdx.x * kPassThreads + threadIdx.x, i)) return;
+    const float x = a.in.x[i], y = a.in.y[i], z = a.in.z[i];
+    const float px = xf_row(a.X.m + 0, x, y, z, 1.0f), py = xf_row(a.X.m + 4, x, y, z, 1.0f), pz = xf_row(a.X.m + 8, x, y, z, 1.0f);
+    Best b;
+    b.pos = a.pos_out[i]; b.d2 = a.d2_out[i]; b.row = 0x7fffffff;
+    if (b.pos >= 0) b.row = __float_as_int(ix.tq[b.pos].w);
+    tree_walk_nf(ix, px, py, pz, b);
+    a.pos_out[i] = b.pos;
+    a.d2_out[i] = b.d2;
 }
 
 // ---------------------------------------------------------------------------
@@ -561,18 +717,19 @@ __device__ __forceinline__ float wave_min_f32(float v)
     return v;
 }
 
-__global__ __launch_bounds__(kPassThreads) void k_search_walk_wave(PassArgs a, TargetIndex ix, const uint32_t *__restrict__ worklist,
-                                                                  const uint32_t *__restrict__ wl_count, uint32_t *overflow,
-                                                                  uint32_t *ov_count, uint32_t kWaveModeMax)
+__global__ __launch_bounds__(kPassThreads) void k_search_walk_wave(PassArgs a, TargetIndex ix, WorkLists wl, uint32_t kWaveModeMax)
 {
     __shared__ uint32_t fr[kPassThreads / 64][2][kWaveFrontier];
-    const uint32_t count = *wl_count;
-    if (count > kWaveModeMax) return;           // long list: k_search_walk does it, one thread per query
+    __shared__ uint32_t pre[kShards + 1];
+    sl_prefix(wl.work, pre);
+    if (pre[kShards] > kWaveModeMax) return;        // long list: k_search_walk does it, one thread per query
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t shard = blockIdx.x & (kShards - 1);
     const uint32_t nwaves = gridDim.x * (kPassThreads / 64);
     const float inf = __int_as_float(0x7f800000);
-    for (uint32_t w = blockIdx.x * (kPassThreads / 64) + wave; w < count; w += nwaves) {
-        const uint32_t i = worklist[w];
+    for (uint32_t w = blockIdx.x * (kPassThreads / 64) + wave; ; w += nwaves) {
+        uint32_t i;
+        if (!sl_locate(wl.work, pre, w, i)) break;
         const float x = a.in.x[i], y = a.in.y[i], z = a.in.z[i];
         const float px = xf_row(a.X.m + 0, x, y, z, 1.0f), py = xf_row(a.X.m + 4, x, y, z, 1.0f), pz = xf_row(a.X.m + 8, x, y, z, 1.0f);
         // wave-uniform best: key = (d2 bits << 32 | row), plus the sorted position of that row
@@ -626,7 +783,7 @@ __global__ __launch_bounds__(kPassThreads) void k_search_walk_wave(PassArgs a, T
             __builtin_amdgcn_wave_barrier();
         }
         if (overflowed) {
-            if (lane == 0) overflow[atomicAdd(ov_count, 1u)] = i;
+            if (lane == 0) sl_push(wl.overflow, shard, i);
             continue;
         }
         // frontier = leaves: 8 leaves x 8 points per batch
@@ -705,14 +862,21 @@ __global__ __launch_bounds__(256) void k_final_reduce(const double *__restrict__
         if (t < off) red[t] += red[t + off];
         __syncthreads();
     }
+    __shared__ int last;
     if (t == 0) {
         out_dev[k] = red[0];
         if (out_host) out_host[k] = red[0];
         // the block that takes the last ticket publishes the sequence number the host spins on
         __threadfence_system();
-        if (atomicAdd(ticket, 1u) == gridDim.x - 1) {
+        last = (atomicAdd(ticket, 1u) == gridDim.x - 1);
+    }
+    __syncthreads();
+    if (last) {
+        // shard counters of the pass's append lists: zero again for the next pass
+        if (counters_to_clear)
+            for (int c = t; c < 3 * kShards; c += 256) counters_to_clear[c * kShardStride] = 0;
+        if (t == 0) {
             *ticket = 0;
-            if (counters_to_clear) { counters_to_clear[0] = 0; counters_to_clear[1] = 0; }
             if (out_host) {
                 __threadfence_system();
                 reinterpret_cast<volatile unsigned long long *>(out_host)[kNSum] = seq;
@@ -809,20 +973,24 @@ void launch_pass_tree(const PassArgs &a, const TargetIndex &ix, int blocks, hipS
     hipLaunchKernelGGL(k_pass_tree, dim3(blocks), dim3(kPassThreads), 0, s, a, ix);
 }
 
-void launch_pass_tree_split(const PassArgs &a, const TargetIndex &ix, uint32_t *worklist, uint32_t *wl_count, int acc_blocks, hipStream_t s)
+uint32_t shard_capacity(uint32_t n_points)
 {
-    static const uint32_t wave_mode_max = getenv("SYMMICP_WAVE_MODE_MAX") ? (uint32_t)atol(getenv("SYMMICP_WAVE_MODE_MAX")) : 65536u;   // work lists longer than this use one thread per query
-    // wl_count[0] (work list) and [1] (overflow list) are zero here: cleared by the previous pass's final reduce
+    // a shard only receives appends from producer blocks with (blockIdx & 63) == shard
+    const uint32_t nb = (n_points + kPassThreads - 1) / kPassThreads;
+    const uint32_t nbp = ((nb + 7u) / 8u) * 8u;
+    return ((nbp + kShards - 1) / kShards) * kPassThreads;
+}
+
+void launch_pass_tree_split(const PassArgs &a, const TargetIndex &ix, const WorkLists &wl, int acc_blocks, hipStream_t s)
+{
+    static const uint32_t wave_mode_max = getenv("SYMMICP_WAVE_MODE_MAX") ? (uint32_t)atol(getenv("SYMMICP_WAVE_MODE_MAX")) : 200000u;   // work lists longer than this use one thread per query
+    // all shard counters are zero here: cleared by the previous pass's final reduce
     const uint32_t nb = (a.n + kPassThreads - 1) / kPassThreads;
     const uint32_t nbp = ((nb + 7u) / 8u) * 8u;
-    hipLaunchKernelGGL(k_search_fast, dim3(nbp), dim3(kPassThreads), 0, s, a, ix, worklist, wl_count);
-    uint32_t wb = nb < 2048u ? nb : 2048u;
-    if (wb < 1u) wb = 1u;
-    uint32_t *overflow = worklist + a.n, *ov_count = wl_count + 1;
-    hipLaunchKernelGGL(k_search_walk_wave, dim3(2048), dim3(kPassThreads), 0, s, a, ix, (const uint32_t *)worklist,
-                       (const uint32_t *)wl_count, overflow, ov_count, wave_mode_max);
-    hipLaunchKernelGGL(k_search_walk, dim3(wb), dim3(kPassThreads), 0, s, a, ix, (const uint32_t *)worklist, (const uint32_t *)wl_count,
-                       (const uint32_t *)overflow, (const uint32_t *)ov_count, wave_mode_max);
+    const uint32_t list_blocks = kShards * (wl.work.cap / kPassThreads);      // one block per (shard, 256-entry chunk)
+    hipLaunchKernelGGL(k_search_cells, dim3(nbp), dim3(kPassThreads), 0, s, a, ix, wl);
+    hipLaunchKernelGGL(k_search_walk_wave, dim3(2048), dim3(kPassThreads), 0, s, a, ix, wl, wave_mode_max);
+    hipLaunchKernelGGL(k_search_walk, dim3(list_blocks), dim3(kPassThreads), 0, s, a, ix, wl, wave_mode_max);
     hipLaunchKernelGGL(k_accumulate, dim3(acc_blocks), dim3(kPassThreads), 0, s, a, ix.tq, ix.tn);
 }
 

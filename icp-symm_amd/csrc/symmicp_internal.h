@@ -53,6 +53,21 @@ struct TargetIndex {
     unsigned long long *dbg; // optional debug counters (SYMMICP_DEBUG_COUNTERS=1), else null
 };
 
+// Append lists for queries a kernel hands to a later kernel of the same pass.  One returning atomic on a single
+// word tops out near 88 per microsecond chip-wide, so a list is 64 shards (counter words 64 B apart); a producer
+// block appends to shard (blockIdx & 63) and consumer block b drains shard (b & 63): same XCD on both sides.
+constexpr int kShards = 64;
+constexpr int kShardStride = 16;          // uint32 words between shard counters
+struct ShardList {
+    uint32_t *items;                      // [kShards][cap]
+    uint32_t *counts;                     // [kShards * kShardStride]
+    uint32_t cap;
+};
+struct WorkLists {
+    ShardList work, overflow, medium;
+    uint32_t *all_counts;                 // the three counter blocks, contiguous: cleared by the final reduce
+};
+
 struct PassArgs {
     // source share (planar).  `in` is read; if writeback, `out` receives the transformed points/normals
     CloudSoA in, out;
@@ -74,7 +89,8 @@ struct PassArgs {
 void launch_pass_identity(const PassArgs &a, CloudSoA tgt, int blocks, hipStream_t s);
 void launch_pass_indexed(const PassArgs &a, const float4 *tq, const float4 *tn, int blocks, hipStream_t s);
 void launch_pass_tree(const PassArgs &a, const TargetIndex &ix, int blocks, hipStream_t s);
-void launch_pass_tree_split(const PassArgs &a, const TargetIndex &ix, uint32_t *worklist, uint32_t *wl_count, int acc_blocks, hipStream_t s);
+void launch_pass_tree_split(const PassArgs &a, const TargetIndex &ix, const WorkLists &wl, int acc_blocks, hipStream_t s);
+uint32_t shard_capacity(uint32_t n_points);
 void launch_final_reduce(const double *partials, int blocks, double *out_dev, double *out_host_mapped, uint32_t *ticket,
                          unsigned long long seq, uint32_t *counters_to_clear, hipStream_t s);
 void launch_publish(const double *sums_dev, double *out_host_mapped, unsigned long long seq, hipStream_t s);
