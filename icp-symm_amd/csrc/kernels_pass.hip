@@ -272,16 +272,21 @@ struct ListStack {
 __device__ __forceinline__ void sorted_child_keys(const float4 *__restrict__ bx, int nchild, float px, float py, float pz,
                                                   float best, uint32_t k[kFan])
 {
-    float4 lo[kFan], hi[kFan];
+    // two halves of four children: 8 loads in flight at a time keeps the register peak (and with it the
+    // occupancy of the latency-bound walk) in check
 #pragma unroll
-    for (int c = 0; c < kFan; c++)
-        if (c < nchild) { lo[c] = bx[2 * c]; hi[c] = bx[2 * c + 1]; }
+    for (int h = 0; h < kFan; h += 4) {
+        float4 lo[4], hi[4];
 #pragma unroll
-    for (int c = 0; c < kFan; c++) {
-        k[c] = kListEmpty;
-        if (c < nchild && lo[c].x <= hi[c].x) {
-            const float d = boxdist2(px, py, pz, lo[c], hi[c]);
-            if (d <= best) k[c] = (__float_as_uint(d) & ~7u) | (uint32_t)c;
+        for (int c = 0; c < 4; c++)
+            if (h + c < nchild) { lo[c] = bx[2 * (h + c)]; hi[c] = bx[2 * (h + c) + 1]; }
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            k[h + c] = kListEmpty;
+            if (h + c < nchild && lo[c].x <= hi[c].x) {
+                const float d = boxdist2(px, py, pz, lo[c], hi[c]);
+                if (d <= best) k[h + c] = (__float_as_uint(d) & ~7u) | (uint32_t)(h + c);
+            }
         }
     }
     SYMMICP_CE(0, 2) SYMMICP_CE(1, 3) SYMMICP_CE(4, 6) SYMMICP_CE(5, 7)
@@ -292,64 +297,79 @@ __device__ __forceinline__ void sorted_child_keys(const float4 *__restrict__ bx,
     SYMMICP_CE(1, 2) SYMMICP_CE(3, 4) SYMMICP_CE(5, 6)
 }
 
+// one step of the walk for one query: at most one node expansion (or leaf-parent scan) followed by at most one
+// sibling advance / climb.  Returns true when the walk is complete.
+__device__ __forceinline__ bool walk_step(const TargetIndex &ix, float px, float py, float pz, Best &b, int &L, uint32_t &i,
+                                          bool &expand, ListStack &st)
+{
+    if (expand) {
+        const int cl = L - 1;
+        const uint32_t cbase = i << 3;
+        uint32_t k[kFan];
+        sorted_child_keys(ix.boxes + 2 * ((size_t)ix.level_off[cl] + cbase), (L == ix.top + 1) ? (int)ix.ntop : kFan,
+                          px, py, pz, b.d2, k);
+        if (cl == 0) {
+            // children are leaves: scan them nearest first; a sorted key already beyond best ends the node
+#pragma unroll
+            for (int q = 0; q < kFan; q++) {
+                if (k[q] == kListEmpty) break;
+                if (__uint_as_float(k[q] & ~7u) > b.d2) break;
+                scan_leaf(ix, cbase + (k[q] & 7u), px, py, pz, b);
+            }
+            // node (L, i) finished
+        } else if (k[0] != kListEmpty) {
+            uint32_t w = 0;
+#pragma unroll
+            for (int q = 1; q < kFan; q++) w |= ((k[q] == kListEmpty) ? 0xFu : (k[q] & 7u)) << (4 * (q - 1));
+            w |= 0xF0000000u;
+            st.push(w);                      // remaining children of (L, i), nearest first
+            L = cl;
+            i = cbase + (k[0] & 7u);
+            return false;                    // next step expands the nearest child
+        }
+    }
+    // (L, i) is finished: next sibling from the list of level L, else climb
+    if (L > ix.top) return true;
+    const uint32_t w = st.s[0];
+    const uint32_t c = w & 0xFu;
+    if (c == 0xFu) {                         // level exhausted -> parent finished
+        st.pop();
+        i >>= 3;
+        L++;
+        expand = false;
+        return false;
+    }
+    st.s[0] = (w >> 4) | 0xF0000000u;
+    const uint32_t sib = (i & ~7u) | c;
+    const float4 *__restrict__ bx = ix.boxes + 2 * ((size_t)ix.level_off[L] + sib);
+    const float d = boxdist2(px, py, pz, bx[0], bx[1]);
+    if (__uint_as_float(__float_as_uint(d) & ~7u) > b.d2) {
+        st.s[0] = kListEmpty;                // sorted: everything after it is at least as far
+        expand = false;
+        return false;
+    }
+    i = sib;
+    expand = (d <= b.d2);                    // within 8 ulp of best but beyond it: skip just this one
+    return false;
+}
+
+__device__ __forceinline__ void walk_init(const TargetIndex &ix, int &L, uint32_t &i, bool &expand, ListStack &st)
+{
+#pragma unroll
+    for (int q = 0; q < 8; q++) st.s[q] = kListEmpty;
+    L = ix.top + 1;                // virtual root above the top level
+    i = 0;
+    expand = true;
+}
+
 __device__ __forceinline__ void tree_walk_nf(const TargetIndex &ix, float px, float py, float pz, Best &b)
 {
     ListStack st;
-#pragma unroll
-    for (int q = 0; q < 8; q++) st.s[q] = kListEmpty;
-    int L = ix.top + 1;            // virtual root above the top level
-    uint32_t i = 0;
-    bool expand = true;
-    while (true) {
-        if (expand) {
-            const int cl = L - 1;
-            const uint32_t cbase = i << 3;
-            uint32_t k[kFan];
-            sorted_child_keys(ix.boxes + 2 * ((size_t)ix.level_off[cl] + cbase), (L == ix.top + 1) ? (int)ix.ntop : kFan,
-                              px, py, pz, b.d2, k);
-            if (cl == 0) {
-                // children are leaves: scan them nearest first; a sorted key already beyond best ends the node
-#pragma unroll
-                for (int q = 0; q < kFan; q++) {
-                    if (k[q] == kListEmpty) break;
-                    if (__uint_as_float(k[q] & ~7u) > b.d2) break;
-                    scan_leaf(ix, cbase + (k[q] & 7u), px, py, pz, b);
-                }
-                // node (L, i) finished
-            } else if (k[0] != kListEmpty) {
-                uint32_t w = 0;
-#pragma unroll
-                for (int q = 1; q < kFan; q++) w |= ((k[q] == kListEmpty) ? 0xFu : (k[q] & 7u)) << (4 * (q - 1));
-                w |= 0xF0000000u;
-                st.push(w);                      // remaining children of (L, i), nearest first
-                L = cl;
-                i = cbase + (k[0] & 7u);
-                continue;                        // expand the nearest child
-            }
-        }
-        // (L, i) is finished: next sibling from the list of level L, else climb
-        if (L > ix.top) break;
-        const uint32_t w = st.s[0];
-        const uint32_t c = w & 0xFu;
-        if (c == 0xFu) {                         // level exhausted -> parent finished
-            st.pop();
-            i >>= 3;
-            L++;
-            expand = false;
-            continue;
-        }
-        st.s[0] = (w >> 4) | 0xF0000000u;
-        const uint32_t sib = (i & ~7u) | c;
-        const float4 *__restrict__ bx = ix.boxes + 2 * ((size_t)ix.level_off[L] + sib);
-        const float d = boxdist2(px, py, pz, bx[0], bx[1]);
-        if (__uint_as_float(__float_as_uint(d) & ~7u) > b.d2) {
-            st.s[0] = kListEmpty;                // sorted: everything after it is at least as far
-            expand = false;
-            continue;
-        }
-        i = sib;
-        expand = (d <= b.d2);                    // within 8 ulp of best but beyond it: skip just this one
-    }
+    int L;
+    uint32_t i;
+    bool expand;
+    walk_init(ix, L, i, expand, st);
+    while (!walk_step(ix, px, py, pz, b, L, i, expand, st)) {}
 }
 
 #undef SYMMICP_CE
@@ -659,8 +679,11 @@ __global__ __launch_bounds__(kPassThreads) void k_search_cells(PassArgs a, Targe
 
 // one thread per query.  Long work lists (far passes) come here directly; for short lists (wave mode) only
 // the overflow list of k_search_walk_wave is left.
-__global__ __launch_bounds__(kPassThreads) void k_search_walk(PassArgs a, TargetIndex ix, WorkLists wl, uint32_t kWaveModeMax)
+__global__ __launch_bounds__(kPassThreads, 6) void k_search_walk(PassArgs a, TargetIndex ix, WorkLists wl, uint32_t kWaveModeMax)
 {
+    // (a persistent variant -- waves owning list chunks, finished lanes refilling from a wave-local cursor -- was
+    //  measured 1.3-2.8x SLOWER on the 1M-query first pass: the walk is latency-bound, and fewer, longer-lived waves
+    //  hide less latency than one short-lived thread per query.)
     __shared__ uint32_t pre[kShards + 1];
     sl_prefix(wl.work, pre);
     const bool wave_mode = pre[kShards] <= kWaveModeMax;      // then only the overflow list is left for this kernel
@@ -987,9 +1010,9 @@ void launch_pass_tree_split(const PassArgs &a, const TargetIndex &ix, const Work
     // all shard counters are zero here: cleared by the previous pass's final reduce
     const uint32_t nb = (a.n + kPassThreads - 1) / kPassThreads;
     const uint32_t nbp = ((nb + 7u) / 8u) * 8u;
-    const uint32_t list_blocks = kShards * (wl.work.cap / kPassThreads);      // one block per (shard, 256-entry chunk)
     hipLaunchKernelGGL(k_search_cells, dim3(nbp), dim3(kPassThreads), 0, s, a, ix, wl);
     hipLaunchKernelGGL(k_search_walk_wave, dim3(2048), dim3(kPassThreads), 0, s, a, ix, wl, wave_mode_max);
+    const uint32_t list_blocks = kShards * (wl.work.cap / kPassThreads);      // enough blocks for one thread per list entry
     hipLaunchKernelGGL(k_search_walk, dim3(list_blocks), dim3(kPassThreads), 0, s, a, ix, wl, wave_mode_max);
     hipLaunchKernelGGL(k_accumulate, dim3(acc_blocks), dim3(kPassThreads), 0, s, a, ix.tq, ix.tn);
 }
