@@ -108,7 +108,11 @@ struct symmicp_ctx {
     symmicp_sums last{};
     // stats
     bool timing = false;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // timing mode: 6 events per pass in a ring of kEvRing passes, resolved lazily (no sync inside the loop)
+    static constexpr int kEvRing = 64, kEvPer = 6;
+    hipEvent_t ev[kEvRing * kEvPer] = {};
+    int ev_split[kEvRing] = {};      // 1 = split TREE pass (5 kernels), 0 = single pass kernel
+    int ev_used = 0;
     symmicp_stats st{};
 };
 
@@ -121,7 +125,7 @@ struct symmicp_ctx {
         }                                                                                                   \
     } while (0)
 
-static double g_t_launch = 0, g_t_spin = 0, g_t_solve = 0, g_t_between = 0, g_t_last_done = 0;
+static double g_t_launch = 0, g_t_spin = 0, g_t_between = 0, g_t_last_done = 0;
 static long g_n_pass = 0;
 
 static int fail(symmicp_ctx *c, int code, const std::string &msg)
@@ -204,7 +208,8 @@ int symmicp_create(const symmicp_config *cfg, symmicp_ctx **out)
               hipMalloc((void **)&c->ticket, sizeof(uint32_t)) == hipSuccess && hipMemset(c->ticket, 0, sizeof(uint32_t)) == hipSuccess &&
               hipHostGetDevicePointer((void **)&c->h_sums_dev, c->h_sums, 0) == hipSuccess &&
               std::memset(c->h_sums, 0, sizeof(double) * (kNSum + 8)) != nullptr &&
-              hipEventCreate(&c->ev0) == hipSuccess && hipEventCreate(&c->ev1) == hipSuccess;
+              true;
+    for (int k = 0; ok && k < symmicp_ctx::kEvRing * symmicp_ctx::kEvPer; k++) ok = hipEventCreate(&c->ev[k]) == hipSuccess;
     if (!ok) { symmicp_destroy(c); return SYMMICP_ERR_HIP; }
     identity16(c->X);
     *out = c;
@@ -238,8 +243,7 @@ void symmicp_destroy(symmicp_ctx *c)
     free_source(c);
     hipFree(c->partials); hipFree(c->d_sums); hipFree(c->ticket);
     if (c->h_sums) hipHostFree(c->h_sums);
-    if (c->ev0) hipEventDestroy(c->ev0);
-    if (c->ev1) hipEventDestroy(c->ev1);
+    for (hipEvent_t e : c->ev) if (e) hipEventDestroy(e);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
 }
@@ -517,6 +521,27 @@ int symmicp_set_source(symmicp_ctx *c, const float *xyz, size_t xr, size_t xc, c
     return SYMMICP_OK;
 }
 
+// resolve the recorded event ring into per-kernel totals (called lazily: ring full, or stats requested)
+static void flush_events(symmicp_ctx *c)
+{
+    for (int p = 0; p < c->ev_used; p++) {
+        hipEvent_t *e = c->ev + p * symmicp_ctx::kEvPer;
+        if (hipEventSynchronize(e[5]) != hipSuccess) continue;
+        float ms = 0.f;
+        double pass_ms = 0.0;
+        if (c->ev_split[p]) {
+            for (int k = 0; k < 5; k++)
+                if (hipEventElapsedTime(&ms, e[k], e[k + 1]) == hipSuccess) { c->st.kernel_ms[k] += ms; c->st.kernel_launches[k]++; if (k < 4) pass_ms += ms; }
+        } else {
+            if (hipEventElapsedTime(&ms, e[0], e[4]) == hipSuccess) { c->st.kernel_ms[5] += ms; c->st.kernel_launches[5]++; pass_ms += ms; }
+            if (hipEventElapsedTime(&ms, e[4], e[5]) == hipSuccess) { c->st.kernel_ms[4] += ms; c->st.kernel_launches[4]++; }
+        }
+        c->st.last_pass_ms = pass_ms;
+        c->st.sum_pass_ms += pass_ms;
+    }
+    c->ev_used = 0;
+}
+
 // ---- one pass over the source share ------------------------------------------------------------
 static int run_pass(symmicp_ctx *c, const float Xapply[16], bool from_cur, bool writeback, bool first)
 {
@@ -545,7 +570,13 @@ static int run_pass(symmicp_ctx *c, const float Xapply[16], bool from_cur, bool 
     c->pass_blocks = blocks;
     const double t_l0 = now_s();
     if (g_t_last_done > 0) g_t_between += t_l0 - g_t_last_done;
-    if (c->timing) hipEventRecord(c->ev0, c->stream);
+    hipEvent_t *ev = nullptr;
+    if (c->timing) {
+        if (c->ev_used == symmicp_ctx::kEvRing) flush_events(c);
+        ev = c->ev + c->ev_used * symmicp_ctx::kEvPer;
+        c->ev_split[c->ev_used] = 0;
+    }
+    if (ev) hipEventRecord(ev[0], c->stream);
     switch (c->cfg.corr) {
     case SYMMICP_CORR_IDENTITY:
         launch_pass_identity(a, c->tgt, blocks, c->stream);
@@ -563,11 +594,12 @@ static int run_pass(symmicp_ctx *c, const float Xapply[16], bool from_cur, bool 
             const int nb_all = (int)((c->n_loc + kPassThreads - 1) / kPassThreads);
             int ab = nb_all < acc_cap ? ((nb_all + 7) / 8) * 8 : acc_cap;
             c->pass_blocks = blocks = ab;
-            launch_pass_tree_split(a, c->ix, c->wl, ab, c->stream);
+            launch_pass_tree_split(a, c->ix, c->wl, ab, c->stream, ev);
+            if (ev) c->ev_split[c->ev_used] = 1;
         }
         break;
     }
-    if (c->timing) hipEventRecord(c->ev1, c->stream);
+    if (ev && !c->ev_split[c->ev_used]) hipEventRecord(ev[4], c->stream);
     const unsigned long long seq = ++c->seq;
     volatile unsigned long long *flag = reinterpret_cast<volatile unsigned long long *>(c->h_sums + kNSum);
     launch_final_reduce(c->partials, blocks, c->d_sums, c->comm ? nullptr : c->h_sums_dev, c->ticket, seq, c->wl_count, c->stream);
@@ -576,6 +608,7 @@ static int run_pass(symmicp_ctx *c, const float Xapply[16], bool from_cur, bool 
         if (r != 0) return fail(c, SYMMICP_ERR_COMM, std::string("ncclAllReduce: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?"));
         launch_publish(c->d_sums, c->h_sums_dev, seq, c->stream);
     }
+    if (ev) { hipEventRecord(ev[5], c->stream); c->ev_used++; }
     // The record arrives in host-mapped memory followed by its sequence number: spin on that word instead of
     // paying a stream-synchronise wake-up per iteration.  A stuck stream (kernel fault) is caught by the fallback.
     g_t_launch += now_s() - t_l0;
@@ -605,11 +638,6 @@ static int run_pass(symmicp_ctx *c, const float Xapply[16], bool from_cur, bool 
         std::fprintf(stderr, "[symmicp dbg] pass %lld: walk=%llu cells=%llu loose_cells_sum=%llu\n", (long long)c->st.passes, h[0], h[1], h[2]);
     }
     std::memcpy(c->last.s, c->h_sums, sizeof(double) * kNSum);
-    if (c->timing) {
-        float ms = 0.f;
-        hipEventSynchronize(c->ev1);
-        if (hipEventElapsedTime(&ms, c->ev0, c->ev1) == hipSuccess) { c->st.last_pass_ms = ms; c->st.sum_pass_ms += ms; }
-    }
     c->st.passes++;
     return SYMMICP_OK;
 }
@@ -874,14 +902,17 @@ int symmicp_enable_timing(symmicp_ctx *c, int on)
 int symmicp_reset_stats(symmicp_ctx *c)
 {
     if (!c) return SYMMICP_ERR_ARG;
+    flush_events(c);
     c->st.last_pass_ms = c->st.sum_pass_ms = 0.0;
     c->st.passes = 0;
+    for (int k = 0; k < 8; k++) { c->st.kernel_ms[k] = 0.0; c->st.kernel_launches[k] = 0; }
     return SYMMICP_OK;
 }
 
 int symmicp_get_stats(symmicp_ctx *c, symmicp_stats *out)
 {
     if (!c || !out) return SYMMICP_ERR_ARG;
+    flush_events(c);
     c->st.pass_blocks = c->pass_blocks;
     const bool incr = resolved_apply(c->cfg) == SYMMICP_APPLY_INCREMENTAL;
     int64_t b = 0;

@@ -679,7 +679,10 @@ __global__ __launch_bounds__(kPassThreads) void k_search_cells(PassArgs a, Targe
 
 // one thread per query.  Long work lists (far passes) come here directly; for short lists (wave mode) only
 // the overflow list of k_search_walk_wave is left.
-__global__ __launch_bounds__(kPassThreads, 6) void k_search_walk(PassArgs a, TargetIndex ix, WorkLists wl, uint32_t kWaveModeMax)
+// one WAVE per block: walk lengths differ several-fold between regions of the cloud, and single-wave blocks let
+// the dispatcher backfill CUs at wave granularity (shorter tail than 4-wave blocks)
+constexpr int kWalkThreads = 64;
+__global__ __launch_bounds__(kWalkThreads) void k_search_walk(PassArgs a, TargetIndex ix, WorkLists wl, uint32_t kWaveModeMax)
 {
     // (a persistent variant -- waves owning list chunks, finished lanes refilling from a wave-local cursor -- was
     //  measured 1.3-2.8x SLOWER on the 1M-query first pass: the walk is latency-bound, and fewer, longer-lived waves
@@ -691,7 +694,7 @@ __global__ __launch_bounds__(kPassThreads, 6) void k_search_walk(PassArgs a, Tar
     if (wave_mode) sl_prefix(wl.overflow, pre);
     const ShardList &L = wave_mode ? wl.overflow : wl.work;
     uint32_t i;
-    if (!sl_locate(L, pre, blockIdx.x * kPassThreads + threadIdx.x, i)) return;
+    if (!sl_locate(L, pre, blockIdx.x * kWalkThreads + threadIdx.x, i)) return;
     const float x = a.in.x[i], y = a.in.y[i], z = a.in.z[i];
     const float px = xf_row(a.X.m + 0, x, y, z, 1.0f), py = xf_row(a.X.m + 4, x, y, z, 1.0f), pz = xf_row(a.X.m + 8, x, y, z, 1.0f);
     Best b;
@@ -1004,17 +1007,22 @@ uint32_t shard_capacity(uint32_t n_points)
     return ((nbp + kShards - 1) / kShards) * kPassThreads;
 }
 
-void launch_pass_tree_split(const PassArgs &a, const TargetIndex &ix, const WorkLists &wl, int acc_blocks, hipStream_t s)
+void launch_pass_tree_split(const PassArgs &a, const TargetIndex &ix, const WorkLists &wl, int acc_blocks, hipStream_t s, hipEvent_t *ev)
 {
     static const uint32_t wave_mode_max = getenv("SYMMICP_WAVE_MODE_MAX") ? (uint32_t)atol(getenv("SYMMICP_WAVE_MODE_MAX")) : 200000u;   // work lists longer than this use one thread per query
     // all shard counters are zero here: cleared by the previous pass's final reduce
     const uint32_t nb = (a.n + kPassThreads - 1) / kPassThreads;
     const uint32_t nbp = ((nb + 7u) / 8u) * 8u;
+    if (ev) hipEventRecord(ev[0], s);
     hipLaunchKernelGGL(k_search_cells, dim3(nbp), dim3(kPassThreads), 0, s, a, ix, wl);
+    if (ev) hipEventRecord(ev[1], s);
     hipLaunchKernelGGL(k_search_walk_wave, dim3(2048), dim3(kPassThreads), 0, s, a, ix, wl, wave_mode_max);
-    const uint32_t list_blocks = kShards * (wl.work.cap / kPassThreads);      // enough blocks for one thread per list entry
-    hipLaunchKernelGGL(k_search_walk, dim3(list_blocks), dim3(kPassThreads), 0, s, a, ix, wl, wave_mode_max);
+    if (ev) hipEventRecord(ev[2], s);
+    const uint32_t list_blocks = kShards * (wl.work.cap / kWalkThreads);      // enough blocks for one thread per list entry
+    hipLaunchKernelGGL(k_search_walk, dim3(list_blocks), dim3(kWalkThreads), 0, s, a, ix, wl, wave_mode_max);
+    if (ev) hipEventRecord(ev[3], s);
     hipLaunchKernelGGL(k_accumulate, dim3(acc_blocks), dim3(kPassThreads), 0, s, a, ix.tq, ix.tn);
+    if (ev) hipEventRecord(ev[4], s);
 }
 
 void launch_final_reduce(const double *partials, int blocks, double *out_dev, double *out_host_mapped, uint32_t *ticket,

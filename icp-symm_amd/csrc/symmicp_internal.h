@@ -89,7 +89,8 @@ struct PassArgs {
 void launch_pass_identity(const PassArgs &a, CloudSoA tgt, int blocks, hipStream_t s);
 void launch_pass_indexed(const PassArgs &a, const float4 *tq, const float4 *tn, int blocks, hipStream_t s);
 void launch_pass_tree(const PassArgs &a, const TargetIndex &ix, int blocks, hipStream_t s);
-void launch_pass_tree_split(const PassArgs &a, const TargetIndex &ix, const WorkLists &wl, int acc_blocks, hipStream_t s);
+// ev: null, or 5 events recorded before cells / after cells / after walk_wave / after walk / after accumulate
+void launch_pass_tree_split(const PassArgs &a, const TargetIndex &ix, const WorkLists &wl, int acc_blocks, hipStream_t s, hipEvent_t *ev);
 uint32_t shard_capacity(uint32_t n_points);
 void launch_final_reduce(const double *partials, int blocks, double *out_dev, double *out_host_mapped, uint32_t *ticket,
                          unsigned long long seq, uint32_t *counters_to_clear, hipStream_t s);

@@ -58,7 +58,11 @@ class Result(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("last_pass_ms", C.c_double), ("sum_pass_ms", C.c_double), ("passes", C.c_int64),
                 ("build_ms", C.c_double), ("upload_ms", C.c_double), ("grid_level", C.c_int32),
-                ("tree_levels", C.c_int32), ("pass_blocks", C.c_int64), ("bytes_algorithmic_per_pass", C.c_int64)]
+                ("tree_levels", C.c_int32), ("pass_blocks", C.c_int64), ("bytes_algorithmic_per_pass", C.c_int64),
+                ("kernel_ms", C.c_double * 8), ("kernel_launches", C.c_int64 * 8)]
+
+
+KERNEL_SLOTS = ["k_search_cells", "k_search_walk_wave", "k_search_walk", "k_accumulate", "k_final_reduce", "single_pass_kernel"]
 
 
 # every symbol include/symmicp.h declares (checked by tests/test_abi.py)
@@ -365,7 +369,10 @@ class Engine:
     def stats(self):
         s = Stats()
         self._chk(self._L.symmicp_get_stats(self._h, C.byref(s)))
-        return {k: getattr(s, k) for k, _ in Stats._fields_}
+        d = {k: getattr(s, k) for k, _ in Stats._fields_}
+        d["kernel_ms"] = list(s.kernel_ms)
+        d["kernel_launches"] = list(s.kernel_launches)
+        return d
 
 
 class MyICP:
