@@ -93,6 +93,7 @@ struct symmicp_ctx {
     uint32_t *src_order = nullptr;   // share position -> row in the caller's cloud (null = identity)
     int32_t *pos = nullptr;
     float *d2 = nullptr;
+    float *cert = nullptr;           // TREE: ref_x, ref_y, ref_z, slack (4 planar arrays)
     unsigned long long *best64 = nullptr;
     uint32_t *worklist = nullptr, *wl_count = nullptr;   // 3 sharded lists + their counters
     WorkLists wl{};
@@ -225,8 +226,8 @@ static void free_target(symmicp_ctx *c)
 
 static void free_source(symmicp_ctx *c)
 {
-    hipFree(c->src0_block); hipFree(c->cur_block); hipFree(c->src_order); hipFree(c->pos); hipFree(c->d2); hipFree(c->best64); hipFree(c->worklist); hipFree(c->wl_count);
-    c->worklist = c->wl_count = nullptr;
+    hipFree(c->src0_block); hipFree(c->cur_block); hipFree(c->src_order); hipFree(c->pos); hipFree(c->d2); hipFree(c->cert); hipFree(c->best64); hipFree(c->worklist); hipFree(c->wl_count);
+    c->worklist = c->wl_count = nullptr; c->cert = nullptr;
     c->src0_block = c->cur_block = nullptr; c->src_order = nullptr; c->pos = nullptr; c->d2 = nullptr; c->best64 = nullptr;
     c->n_loc = c->n_s_total = c->src_off = 0;
 }
@@ -506,6 +507,8 @@ int symmicp_set_source(symmicp_ctx *c, const float *xyz, size_t xr, size_t xc, c
     HIP_TRY(c, hipMalloc((void **)&c->d2, sizeof(float) * nl));
     if (c->cfg.corr == SYMMICP_CORR_BRUTE) HIP_TRY(c, hipMalloc((void **)&c->best64, sizeof(unsigned long long) * nl));
     if (c->cfg.corr == SYMMICP_CORR_TREE) {
+        HIP_TRY(c, hipMalloc((void **)&c->cert, sizeof(float) * 4 * nl));
+        HIP_TRY(c, hipMemset(c->cert, 0, sizeof(float) * 4 * nl));
         const uint32_t cap = shard_capacity(nl);
         const size_t per_list = (size_t)kShards * cap, ncount = (size_t)kShards * kShardStride;
         HIP_TRY(c, hipMalloc((void **)&c->worklist, sizeof(uint32_t) * 3 * per_list));      // work, overflow, medium
@@ -561,6 +564,12 @@ static int run_pass(symmicp_ctx *c, const float Xapply[16], bool from_cur, bool 
     a.pos_out = c->pos;
     a.d2_out = c->d2;
     a.partials = c->partials;
+    {
+        const uint32_t nl = c->n_loc > 0 ? c->n_loc : 1;
+        a.ref_x = c->cert; a.ref_y = c->cert ? c->cert + nl : nullptr; a.ref_z = c->cert ? c->cert + 2 * (size_t)nl : nullptr;
+        a.slack = c->cert ? c->cert + 3 * (size_t)nl : nullptr;
+        a.use_slack = (!first && c->cert && !std::getenv("SYMMICP_NO_CERT")) ? 1 : 0;
+    }
     int blocks = (int)((c->n_loc + kPassThreads - 1) / kPassThreads);
     int cap = 2048;
     if (const char *e = std::getenv("SYMMICP_PASS_BLOCKS")) cap = std::atoi(e);

@@ -535,11 +535,22 @@ __device__ __forceinline__ float axis_gap2(float p, float origin, int c, float h
 //   phase 3  thread = query: store the pair.
 // A wave's cost is now the largest single CELL in it, not the largest sum over a query's cells, and queries with 27
 // cells no longer drag their whole wave through 27 steps.
+//
+// Pair certificates.  The search ball is padded by D = kSlackFrac * h beyond the previous pair's distance, so after
+// the scan every target point other than the winner is known to be at least L = min(second-nearest scanned, bound + D)
+// away from the query position p_ref.  If the query later sits at p with |p - p_ref| = delta, any other point is
+// >= L - delta away and the old winner <= d1 + delta, so while 2*delta < L - d1 (=: slack) the nearest neighbour is
+// provably the same point and the scan is skipped; only its distance is refreshed.  Once ICP has converged almost
+// every pair is certified and the kernel is little more than phase 1.  Margins of 1e-5 relative cover fp32 rounding
+// (distance evaluations are good to ~4e-7); exact ties give slack 0 and are always searched again.
 // ---------------------------------------------------------------------------
+constexpr float kSlackFrac = 0.25f;
+
 __global__ __launch_bounds__(kPassThreads) void k_search_cells(PassArgs a, TargetIndex ix, WorkLists wl)
 {
     __shared__ float s_px[kPassThreads], s_py[kPassThreads], s_pz[kPassThreads];
     __shared__ unsigned long long s_key[kPassThreads];
+    __shared__ uint32_t s_second[kPassThreads];        // d2 bits of the second-nearest scanned point
     __shared__ int32_t s_pos[kPassThreads];
     __shared__ uint32_t s_cell0[kPassThreads];
     __shared__ uint16_t s_items[kPassThreads * 27];
@@ -549,62 +560,79 @@ __global__ __launch_bounds__(kPassThreads) void k_search_cells(PassArgs a, Targe
     const uint32_t shard = blockIdx.x & (kShards - 1);
     const uint32_t i = xcd_remap(blockIdx.x, gridDim.x) * kPassThreads + tid;
     const bool active = i < a.n;
+    const float inf = __int_as_float(0x7f800000);
 
     // ---- phase 1 ----
     float px = 0.f, py = 0.f, pz = 0.f;
     Best b;
-    b.d2 = __int_as_float(0x7f800000); b.pos = -1; b.row = 0x7fffffff;
+    b.d2 = inf; b.pos = -1; b.row = 0x7fffffff;
     uint32_t mask = 0;                 // surviving cells of this query, bit = kx + 3*ky + 9*kz
-    bool defer = false;
+    bool defer = false, searched = false;
+    float lim = 0.f;                   // bound + D: everything outside the scanned cells is at least this far
     if (active) {
         const float x = a.in.x[i], y = a.in.y[i], z = a.in.z[i];
         const int32_t prev = a.pos_prev ? a.pos_prev[i] : -1;
         px = xf_row(a.X.m + 0, x, y, z, 1.0f); py = xf_row(a.X.m + 4, x, y, z, 1.0f); pz = xf_row(a.X.m + 8, x, y, z, 1.0f);
         if (prev >= 0 && (uint32_t)prev < ix.n) test_point(b, ix.tq[prev], prev, px, py, pz);
-        defer = true;
-        if (b.pos >= 0 && ix.glevel > 0) {
-            const float margin = 2e-3f * ix.h;
-            const float gmax = (float)ix.gdim;
-            // any r >= sqrt(d2) is valid here: the hardware square root (1 ulp) with a relative pad
-            const float r = __builtin_amdgcn_sqrtf(b.d2) * 1.00001f + margin;
-            const float lx = (px - r - ix.ox) * ix.inv_h, hx = (px + r - ix.ox) * ix.inv_h;
-            const float ly = (py - r - ix.oy) * ix.inv_h, hy = (py + r - ix.oy) * ix.inv_h;
-            const float lz = (pz - r - ix.oz) * ix.inv_h, hz = (pz + r - ix.oz) * ix.inv_h;
-            const int x0 = (int)floorf(fminf(fmaxf(lx, 0.0f), gmax - 1.0f)), x1 = (int)floorf(fminf(fmaxf(hx, 0.0f), gmax - 1.0f));
-            const int y0 = (int)floorf(fminf(fmaxf(ly, 0.0f), gmax - 1.0f)), y1 = (int)floorf(fminf(fmaxf(hy, 0.0f), gmax - 1.0f));
-            const int z0 = (int)floorf(fminf(fmaxf(lz, 0.0f), gmax - 1.0f)), z1 = (int)floorf(fminf(fmaxf(hz, 0.0f), gmax - 1.0f));
-            const int nx = x1 - x0, ny = y1 - y0, nz = z1 - z0;      // extra cells per axis
-            if (nx <= 2 && ny <= 2 && nz <= 2) {
-                defer = false;
-                const float inf = __int_as_float(0x7f800000);
-                float gx[3], gy[3], gz[3];
-#pragma unroll
-                for (int k = 0; k < 3; k++) {
-                    gx[k] = (k <= nx) ? axis_gap2(px, ix.ox, x0 + k, ix.h, margin) : inf;
-                    gy[k] = (k <= ny) ? axis_gap2(py, ix.oy, y0 + k, ix.h, margin) : inf;
-                    gz[k] = (k <= nz) ? axis_gap2(pz, ix.oz, z0 + k, ix.h, margin) : inf;
-                }
-#pragma unroll
-                for (int kz = 0; kz < 3; kz++)
-#pragma unroll
-                    for (int ky = 0; ky < 3; ky++)
-#pragma unroll
-                        for (int kx = 0; kx < 3; kx++) {
-                            const float g2 = (gx[kx] + gy[ky]) + gz[kz];
-                            if (g2 <= b.d2) mask |= 1u << (kx + 3 * ky + 9 * kz);
-                        }
-                s_cell0[tid] = (uint32_t)x0 | ((uint32_t)y0 << 10) | ((uint32_t)z0 << 20);
-            }
+        bool certified = false;
+        if (a.use_slack && b.pos >= 0) {
+            const float sl = a.slack[i];
+            const float m2 = dist2(px, py, pz, a.ref_x[i], a.ref_y[i], a.ref_z[i]);      // delta^2
+            certified = (4.0f * m2) * 1.00002f < sl * sl;
         }
-        if (defer) {
-            a.pos_out[i] = b.pos;        // provisional: the tree walk starts from this bound
-            a.d2_out[i] = b.d2;
-            sl_push(wl.work, shard, i);
+        if (certified) {
+            a.d2_out[i] = b.d2;          // same pair, refreshed distance; position, certificate unchanged
+        } else {
+            defer = true;
+            if (b.pos >= 0 && ix.glevel > 0) {
+                const float margin = 2e-3f * ix.h;
+                const float gmax = (float)ix.gdim;
+                // any rb >= sqrt(d2) is valid: the hardware square root (1 ulp) with a relative pad
+                const float rb = __builtin_amdgcn_sqrtf(b.d2) * 1.00001f;
+                lim = rb + kSlackFrac * ix.h;
+                const float r = lim + margin;
+                const float lx = (px - r - ix.ox) * ix.inv_h, hx = (px + r - ix.ox) * ix.inv_h;
+                const float ly = (py - r - ix.oy) * ix.inv_h, hy = (py + r - ix.oy) * ix.inv_h;
+                const float lz = (pz - r - ix.oz) * ix.inv_h, hz = (pz + r - ix.oz) * ix.inv_h;
+                const int x0 = (int)floorf(fminf(fmaxf(lx, 0.0f), gmax - 1.0f)), x1 = (int)floorf(fminf(fmaxf(hx, 0.0f), gmax - 1.0f));
+                const int y0 = (int)floorf(fminf(fmaxf(ly, 0.0f), gmax - 1.0f)), y1 = (int)floorf(fminf(fmaxf(hy, 0.0f), gmax - 1.0f));
+                const int z0 = (int)floorf(fminf(fmaxf(lz, 0.0f), gmax - 1.0f)), z1 = (int)floorf(fminf(fmaxf(hz, 0.0f), gmax - 1.0f));
+                const int nx = x1 - x0, ny = y1 - y0, nz = z1 - z0;      // extra cells per axis
+                if (nx <= 2 && ny <= 2 && nz <= 2) {
+                    defer = false;
+                    searched = true;
+                    const float thr2 = lim * lim * 1.00001f;             // keep every cell that reaches into the padded ball
+                    float gx[3], gy[3], gz[3];
+#pragma unroll
+                    for (int k = 0; k < 3; k++) {
+                        gx[k] = (k <= nx) ? axis_gap2(px, ix.ox, x0 + k, ix.h, margin) : inf;
+                        gy[k] = (k <= ny) ? axis_gap2(py, ix.oy, y0 + k, ix.h, margin) : inf;
+                        gz[k] = (k <= nz) ? axis_gap2(pz, ix.oz, z0 + k, ix.h, margin) : inf;
+                    }
+#pragma unroll
+                    for (int kz = 0; kz < 3; kz++)
+#pragma unroll
+                        for (int ky = 0; ky < 3; ky++)
+#pragma unroll
+                            for (int kx = 0; kx < 3; kx++) {
+                                const float g2 = (gx[kx] + gy[ky]) + gz[kz];
+                                if (g2 <= thr2) mask |= 1u << (kx + 3 * ky + 9 * kz);
+                            }
+                    s_cell0[tid] = (uint32_t)x0 | ((uint32_t)y0 << 10) | ((uint32_t)z0 << 20);
+                }
+            }
+            if (defer) {
+                a.pos_out[i] = b.pos;        // provisional: the tree walk starts from this bound
+                a.d2_out[i] = b.d2;
+                a.slack[i] = 0.0f;           // pairs found by the walk carry no certificate
+                sl_push(wl.work, shard, i);
+            }
         }
     }
     s_px[tid] = px; s_py[tid] = py; s_pz[tid] = pz;
     s_pos[tid] = b.pos;
     s_key[tid] = (b.pos >= 0) ? (((unsigned long long)__float_as_uint(b.d2) << 32) | (unsigned long long)(uint32_t)b.row) : ~0ull;
+    s_second[tid] = 0x7f800000u;
     // block-wide exclusive prefix sum of the item counts
     const uint32_t cnt = (uint32_t)__popc(mask);
     uint32_t incl = cnt;
@@ -637,6 +665,7 @@ __global__ __launch_bounds__(kPassThreads) void k_search_cells(PassArgs a, Targe
     for (uint32_t it0 = 0; it0 < total; it0 += kPassThreads) {
         const uint32_t it = it0 + tid;
         unsigned long long mykey = ~0ull;
+        uint32_t my2nd = 0x7f800000u;          // d2 bits of this item's second-nearest point
         int32_t mypos = -1;
         int q = 0;
         if (it < total) {
@@ -648,20 +677,33 @@ __global__ __launch_bounds__(kPassThreads) void k_search_cells(PassArgs a, Targe
             const uint32_t cx = (c0 & 1023u) + (uint32_t)kx, cy = ((c0 >> 10) & 1023u) + (uint32_t)ky, cz = (c0 >> 20) + (uint32_t)kz;
             const uint2 rng = ix.cells[(spread3(cz) << 2) | (spread3(cy) << 1) | spread3(cx)];
             const float qx = s_px[q], qy = s_py[q], qz = s_pz[q];
-            Best lb;
-            lb.d2 = __int_as_float(0x7f800000); lb.pos = -1; lb.row = 0x7fffffff;
             for (uint32_t j = rng.x; j < rng.y; j += 4) {
                 float4 t4[4];
 #pragma unroll
                 for (int k = 0; k < 4; k++) t4[k] = ix.tq[min(j + (uint32_t)k, rng.y - 1)];
 #pragma unroll
-                for (int k = 0; k < 4; k++)
-                    if (j + (uint32_t)k < rng.y) test_point(lb, t4[k], (int32_t)(j + k), qx, qy, qz);
+                for (int k = 0; k < 4; k++) {
+                    if (j + (uint32_t)k < rng.y) {
+                        const float d2 = dist2(qx, qy, qz, t4[k].x, t4[k].y, t4[k].z);
+                        if (d2 == d2) {
+                            const unsigned long long key = ((unsigned long long)__float_as_uint(d2) << 32) |
+                                                           (unsigned long long)(uint32_t)__float_as_int(t4[k].w);
+                            if (key < mykey) { my2nd = (uint32_t)(mykey >> 32); mykey = key; mypos = (int32_t)(j + k); }
+                            else my2nd = min(my2nd, __float_as_uint(d2));
+                        }
+                    }
+                }
             }
-            if (lb.pos >= 0) {
-                mykey = ((unsigned long long)__float_as_uint(lb.d2) << 32) | (unsigned long long)(uint32_t)lb.row;
-                mypos = lb.pos;
-                atomicMin(&s_key[q], mykey);
+            if (mypos >= 0) {
+                // Every key that loses against the running minimum -- ours, or the one we displace -- is a candidate for
+                // the query's second-nearest distance; the final winner is the only key never offered.  (Deciding
+                // "am I the winner" per round would be wrong: a later round can still displace this round's winner.)
+                const unsigned long long old = atomicMin(&s_key[q], mykey);
+                uint32_t offer;
+                if (mykey < old) offer = min((uint32_t)(old >> 32), my2nd);
+                else if (mykey == old) offer = my2nd;              // the previous pair found again in its cell
+                else offer = (uint32_t)(mykey >> 32);
+                atomicMin(&s_second[q], offer);
             }
         }
         __syncthreads();
@@ -670,10 +712,17 @@ __global__ __launch_bounds__(kPassThreads) void k_search_cells(PassArgs a, Targe
     __syncthreads();
 
     // ---- phase 3 ----
-    if (active && !defer) {
+    if (active && searched) {
         const unsigned long long key = s_key[tid];
+        const float d1sq = __uint_as_float((uint32_t)(key >> 32));
         a.pos_out[i] = s_pos[tid];
-        a.d2_out[i] = __uint_as_float((uint32_t)(key >> 32));
+        a.d2_out[i] = d1sq;
+        // certificate for the following passes
+        const float d1 = sqrtf(d1sq) * 1.00001f;
+        const float second = sqrtf(__uint_as_float(s_second[tid])) * 0.99999f;
+        const float L = fminf(second, lim * 0.99999f);
+        a.ref_x[i] = px; a.ref_y[i] = py; a.ref_z[i] = pz;
+        a.slack[i] = fmaxf(L - d1, 0.0f);
     }
 }
 

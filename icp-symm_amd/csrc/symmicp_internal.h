@@ -82,7 +82,11 @@ struct PassArgs {
     int32_t *pos_prev;                  // TREE: sorted position found by the previous pass (-1 = none); updated
     float *d2_out;                      // optional per-point squared distance (may be null)
     int32_t *pos_out;                   // sorted position / target row chosen this pass (may alias pos_prev)
-    double *partials;                   // [blocks][kNSum]
+    double *partials;                   // [kNSum][blocks] (transposed)
+    // pair certificates (TREE): position of the query when its pair was last searched, and how far it may move
+    // before the pair has to be searched again (see k_search_cells)
+    float *ref_x, *ref_y, *ref_z, *slack;
+    int32_t use_slack;                  // 0 on the first pass of an alignment (certificates not valid yet)
 };
 
 // ---- kernel launchers (kernels.hip) ---------------------------------------

@@ -171,7 +171,7 @@ def test_tree_follows_previous_pairs_across_iterations(sym, oracle):
         e.set_target(d["tgt"], d["tgt_n"])
         e.set_source(d["src"], d["src_n"])
         e.begin()
-        for _ in range(4):
+        for _ in range(8):      # later passes run almost entirely on pair certificates (no re-search)
             e.step()
             idx, d2 = e.correspondences()
             p, _ = e.source()
@@ -459,3 +459,27 @@ def test_rccl_path_single_rank_communicator(sym, cat, monkeypatch):
         r1 = e.align()
     assert r1["status"] == 0 and np.array_equal(r0["transform"], r1["transform"])
     assert r0["diff_final"] == r1["diff_final"]
+
+
+def test_pair_certificates_stay_exact_under_small_and_large_moves(sym, oracle):
+    """Pair certificates (k_search_cells): after a search a pair is re-used while the query has provably not
+    moved far enough to change its nearest neighbour.  Drive the engine with a sequence of tiny and not-so-tiny
+    rigid nudges (via begin(guess) -> step) and check every pass against brute-force-exact NN."""
+    from symmicp import synth
+    d = synth.c4_surface(60000)
+    rng = np.random.default_rng(7)
+    with sym.Engine(mode=sym.MODE_PAPER, corr=sym.CORR_TREE, apply=sym.APPLY_INCREMENTAL) as e:
+        e.set_target(d["tgt"], d["tgt_n"])
+        e.set_source(d["src"], d["src_n"])
+        G = d["truth"].astype(np.float32).copy()
+        G[:3, 3] += np.float32([2e-3, -1e-3, 1e-3])        # start near, but not at, the optimum
+        e.begin(G)
+        n_cert = []
+        for it in range(10):
+            e.step()
+            idx, d2 = e.correspondences()
+            p, _ = e.source()
+            ri, rd = oracle.nn_grid(p, d["tgt"])
+            bad = np.nonzero(idx != ri)[0]
+            assert bad.size == 0, (it, bad[:5], idx[bad[:5]], ri[bad[:5]])
+            assert np.array_equal(d2, rd)
