@@ -567,8 +567,8 @@ __global__ __launch_bounds__(kPassThreads) void k_search_cells(PassArgs a, Targe
     Best b;
     b.d2 = inf; b.pos = -1; b.row = 0x7fffffff;
     uint32_t mask = 0;                 // surviving cells of this query, bit = kx + 3*ky + 9*kz
-    bool defer = false, searched = false;
-    float lim = 0.f;                   // bound + D: everything outside the scanned cells is at least this far
+    bool defer = false, searched = false, probe = false;
+    float lim = 0.f;                   // everything outside the scanned cells is at least this far from the query
     if (active) {
         const float x = a.in.x[i], y = a.in.y[i], z = a.in.z[i];
         const int32_t prev = a.pos_prev ? a.pos_prev[i] : -1;
@@ -619,6 +619,39 @@ __global__ __launch_bounds__(kPassThreads) void k_search_cells(PassArgs a, Targe
                                 if (g2 <= thr2) mask |= 1u << (kx + 3 * ky + 9 * kz);
                             }
                     s_cell0[tid] = (uint32_t)x0 | ((uint32_t)y0 << 10) | ((uint32_t)z0 << 20);
+                }
+            }
+            if (defer && b.pos >= 0 && ix.glevel > 0) {
+                // The previous pair is too far to bound the scan (the cloud has just moved a lot).  Probe the 27 cells
+                // around the query instead: if the best point found there is closer than the nearest outer face of that
+                // block, nothing outside the block can beat it and the answer is exact; otherwise it still tightens the
+                // bound the tree walk starts from.  Only queries inside the grid probe.
+                const float fx = (px - ix.ox) * ix.inv_h, fy = (py - ix.oy) * ix.inv_h, fz = (pz - ix.oz) * ix.inv_h;
+                const float gmax = (float)ix.gdim;
+                if (fx >= 0.0f && fy >= 0.0f && fz >= 0.0f && fx < gmax && fy < gmax && fz < gmax) {
+                    const int cx = (int)fx, cy = (int)fy, cz = (int)fz;
+                    const int x0 = max(cx - 1, 0), y0 = max(cy - 1, 0), z0 = max(cz - 1, 0);
+                    const int x1 = min(cx + 1, ix.gdim - 1), y1 = min(cy + 1, ix.gdim - 1), z1 = min(cz + 1, ix.gdim - 1);
+                    const int nx = x1 - x0, ny = y1 - y0, nz = z1 - z0;
+#pragma unroll
+                    for (int kz = 0; kz < 3; kz++)
+#pragma unroll
+                        for (int ky = 0; ky < 3; ky++)
+#pragma unroll
+                            for (int kx = 0; kx < 3; kx++)
+                                if (kx <= nx && ky <= ny && kz <= nz) mask |= 1u << (kx + 3 * ky + 9 * kz);
+                    s_cell0[tid] = (uint32_t)x0 | ((uint32_t)y0 << 10) | ((uint32_t)z0 << 20);
+                    // distance from the query to the nearest face of the block that has cells beyond it
+                    float face = inf;
+                    if (x0 > 0) face = fminf(face, px - (ix.ox + (float)x0 * ix.h));
+                    if (y0 > 0) face = fminf(face, py - (ix.oy + (float)y0 * ix.h));
+                    if (z0 > 0) face = fminf(face, pz - (ix.oz + (float)z0 * ix.h));
+                    if (x1 < ix.gdim - 1) face = fminf(face, (ix.ox + (float)(x1 + 1) * ix.h) - px);
+                    if (y1 < ix.gdim - 1) face = fminf(face, (ix.oy + (float)(y1 + 1) * ix.h) - py);
+                    if (z1 < ix.gdim - 1) face = fminf(face, (ix.oz + (float)(z1 + 1) * ix.h) - pz);
+                    lim = face - 2e-3f * ix.h;      // everything outside the block is at least this far away
+                    probe = true;
+                    defer = false;
                 }
             }
             if (defer) {
@@ -712,17 +745,23 @@ __global__ __launch_bounds__(kPassThreads) void k_search_cells(PassArgs a, Targe
     __syncthreads();
 
     // ---- phase 3 ----
-    if (active && searched) {
+    if (active && (searched || probe)) {
         const unsigned long long key = s_key[tid];
         const float d1sq = __uint_as_float((uint32_t)(key >> 32));
+        const float d1 = sqrtf(d1sq) * 1.00001f;
         a.pos_out[i] = s_pos[tid];
         a.d2_out[i] = d1sq;
-        // certificate for the following passes
-        const float d1 = sqrtf(d1sq) * 1.00001f;
-        const float second = sqrtf(__uint_as_float(s_second[tid])) * 0.99999f;
-        const float L = fminf(second, lim * 0.99999f);
-        a.ref_x[i] = px; a.ref_y[i] = py; a.ref_z[i] = pz;
-        a.slack[i] = fmaxf(L - d1, 0.0f);
+        if (probe && !(d1 < lim)) {
+            // the probe could not prove its best: the tree walk takes over from this (tighter) bound
+            a.slack[i] = 0.0f;
+            sl_push(wl.work, shard, i);
+        } else {
+            // certificate for the following passes
+            const float second = sqrtf(__uint_as_float(s_second[tid])) * 0.99999f;
+            const float L = fminf(second, lim * 0.99999f);
+            a.ref_x[i] = px; a.ref_y[i] = py; a.ref_z[i] = pz;
+            a.slack[i] = fmaxf(L - d1, 0.0f);
+        }
     }
 }
 
