@@ -587,9 +587,18 @@ static int run_pass(symmicp_ctx *c, const float Xapply[16], bool from_cur, bool 
     }
     if (ev) hipEventRecord(ev[0], c->stream);
     switch (c->cfg.corr) {
-    case SYMMICP_CORR_IDENTITY:
-        launch_pass_identity(a, c->tgt, blocks, c->stream);
+    case SYMMICP_CORR_IDENTITY: {
+        // 16-byte column loads need every planar column (length n_loc / n_t) and the shard offset to keep 16-B alignment
+        const bool vec4 = (c->n_loc % 4 == 0) && (c->n_t % 4 == 0) && (c->src_off % 4 == 0);
+        if (vec4) {
+            static const int id_cap = std::getenv("SYMMICP_ID_BLOCKS") ? std::atoi(std::getenv("SYMMICP_ID_BLOCKS")) : 2048;
+            const int nb4 = (int)((c->n_loc / 4 + kPassThreads - 1) / kPassThreads);
+            blocks = nb4 < id_cap ? (nb4 > 0 ? nb4 : 1) : id_cap;
+            c->pass_blocks = blocks;
+        }
+        launch_pass_identity(a, c->tgt, blocks, vec4, c->stream);
         break;
+    }
     case SYMMICP_CORR_BRUTE:
         launch_nn_brute(a.in, c->n_loc, a.X, c->tq, c->n_t, c->best64, c->stream);
         launch_pass_indexed(a, c->tq, c->tn, blocks, c->stream);

@@ -133,26 +133,67 @@ __device__ __forceinline__ void acc_block_reduce_store(Acc &a, double *partials,
 // pass, identity pairing (what the reference does: myicp.cpp:130)
 // Streaming: 48 B/point read (+24 B/point written with write-back).
 // ---------------------------------------------------------------------------
+// VEC = 4: each thread handles 4 consecutive points per step with 16-byte loads/stores from the planar
+// arrays (needs n, the target offset and the array lengths to be multiples of 4 so every column stays
+// 16-byte aligned); VEC = 1 is the general form.
+template <int VEC>
 __global__ __launch_bounds__(kPassThreads) void k_pass_identity(PassArgs a, CloudSoA tgt)
 {
     Acc acc; acc_zero(acc);
-    const uint32_t stride = gridDim.x * blockDim.x;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += stride) {
-        float x = a.in.x[i], y = a.in.y[i], z = a.in.z[i];
-        float nx = a.in.nx[i], ny = a.in.ny[i], nz = a.in.nz[i];
-        float px = xf_row(a.X.m + 0, x, y, z, 1.0f), py = xf_row(a.X.m + 4, x, y, z, 1.0f), pz = xf_row(a.X.m + 8, x, y, z, 1.0f);
-        float npx = xf_row(a.X.m + 0, nx, ny, nz, a.X.nrm_w), npy = xf_row(a.X.m + 4, nx, ny, nz, a.X.nrm_w),
-              npz = xf_row(a.X.m + 8, nx, ny, nz, a.X.nrm_w);
-        if (a.writeback) {
-            a.out.x[i] = px; a.out.y[i] = py; a.out.z[i] = pz;
-            a.out.nx[i] = npx; a.out.ny[i] = npy; a.out.nz[i] = npz;
+    const uint32_t stride = gridDim.x * blockDim.x * VEC;
+    for (uint32_t i0 = (blockIdx.x * blockDim.x + threadIdx.x) * VEC; i0 < a.n; i0 += stride) {
+        float x[VEC], y[VEC], z[VEC], nx[VEC], ny[VEC], nz[VEC], qx[VEC], qy[VEC], qz[VEC], qnx[VEC], qny[VEC], qnz[VEC];
+        const uint32_t j0 = a.tgt_offset + i0;
+        if (VEC == 4) {
+            *reinterpret_cast<float4 *>(x) = *reinterpret_cast<const float4 *>(a.in.x + i0);
+            *reinterpret_cast<float4 *>(y) = *reinterpret_cast<const float4 *>(a.in.y + i0);
+            *reinterpret_cast<float4 *>(z) = *reinterpret_cast<const float4 *>(a.in.z + i0);
+            *reinterpret_cast<float4 *>(nx) = *reinterpret_cast<const float4 *>(a.in.nx + i0);
+            *reinterpret_cast<float4 *>(ny) = *reinterpret_cast<const float4 *>(a.in.ny + i0);
+            *reinterpret_cast<float4 *>(nz) = *reinterpret_cast<const float4 *>(a.in.nz + i0);
+            *reinterpret_cast<float4 *>(qx) = *reinterpret_cast<const float4 *>(tgt.x + j0);
+            *reinterpret_cast<float4 *>(qy) = *reinterpret_cast<const float4 *>(tgt.y + j0);
+            *reinterpret_cast<float4 *>(qz) = *reinterpret_cast<const float4 *>(tgt.z + j0);
+            *reinterpret_cast<float4 *>(qnx) = *reinterpret_cast<const float4 *>(tgt.nx + j0);
+            *reinterpret_cast<float4 *>(qny) = *reinterpret_cast<const float4 *>(tgt.ny + j0);
+            *reinterpret_cast<float4 *>(qnz) = *reinterpret_cast<const float4 *>(tgt.nz + j0);
+        } else {
+            x[0] = a.in.x[i0]; y[0] = a.in.y[i0]; z[0] = a.in.z[i0];
+            nx[0] = a.in.nx[i0]; ny[0] = a.in.ny[i0]; nz[0] = a.in.nz[i0];
+            qx[0] = tgt.x[j0]; qy[0] = tgt.y[j0]; qz[0] = tgt.z[j0];
+            qnx[0] = tgt.nx[j0]; qny[0] = tgt.ny[j0]; qnz[0] = tgt.nz[j0];
         }
-        uint32_t j = a.tgt_offset + i;
-        float qx = tgt.x[j], qy = tgt.y[j], qz = tgt.z[j];
-        float d2 = dist2(px, py, pz, qx, qy, qz);
-        if (a.d2_out) a.d2_out[i] = d2;
-        if (a.max_d2 > 0.0f && d2 > a.max_d2) continue;
-        acc_pair(acc, px, py, pz, npx, npy, npz, qx, qy, qz, tgt.nx[j], tgt.ny[j], tgt.nz[j], d2, a.pivot);
+        float px[VEC], py[VEC], pz[VEC], npx[VEC], npy[VEC], npz[VEC], d2[VEC];
+#pragma unroll
+        for (int k = 0; k < VEC; k++) {
+            px[k] = xf_row(a.X.m + 0, x[k], y[k], z[k], 1.0f); py[k] = xf_row(a.X.m + 4, x[k], y[k], z[k], 1.0f);
+            pz[k] = xf_row(a.X.m + 8, x[k], y[k], z[k], 1.0f);
+            npx[k] = xf_row(a.X.m + 0, nx[k], ny[k], nz[k], a.X.nrm_w); npy[k] = xf_row(a.X.m + 4, nx[k], ny[k], nz[k], a.X.nrm_w);
+            npz[k] = xf_row(a.X.m + 8, nx[k], ny[k], nz[k], a.X.nrm_w);
+            d2[k] = dist2(px[k], py[k], pz[k], qx[k], qy[k], qz[k]);
+        }
+        if (a.writeback) {
+            if (VEC == 4) {
+                *reinterpret_cast<float4 *>(a.out.x + i0) = *reinterpret_cast<float4 *>(px);
+                *reinterpret_cast<float4 *>(a.out.y + i0) = *reinterpret_cast<float4 *>(py);
+                *reinterpret_cast<float4 *>(a.out.z + i0) = *reinterpret_cast<float4 *>(pz);
+                *reinterpret_cast<float4 *>(a.out.nx + i0) = *reinterpret_cast<float4 *>(npx);
+                *reinterpret_cast<float4 *>(a.out.ny + i0) = *reinterpret_cast<float4 *>(npy);
+                *reinterpret_cast<float4 *>(a.out.nz + i0) = *reinterpret_cast<float4 *>(npz);
+            } else {
+                a.out.x[i0] = px[0]; a.out.y[i0] = py[0]; a.out.z[i0] = pz[0];
+                a.out.nx[i0] = npx[0]; a.out.ny[i0] = npy[0]; a.out.nz[i0] = npz[0];
+            }
+        }
+        if (a.d2_out) {
+            if (VEC == 4) *reinterpret_cast<float4 *>(a.d2_out + i0) = *reinterpret_cast<float4 *>(d2);
+            else a.d2_out[i0] = d2[0];
+        }
+#pragma unroll
+        for (int k = 0; k < VEC; k++) {
+            if (a.max_d2 > 0.0f && d2[k] > a.max_d2) continue;
+            acc_pair(acc, px[k], py[k], pz[k], npx[k], npy[k], npz[k], qx[k], qy[k], qz[k], qnx[k], qny[k], qnz[k], d2[k], a.pivot);
+        }
     }
     acc_block_reduce_store(acc, a.partials, gridDim.x);
 }
@@ -1072,9 +1113,10 @@ __global__ __launch_bounds__(kPassThreads) void k_nn_brute(CloudSoA src, uint32_
 // ---------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------
-void launch_pass_identity(const PassArgs &a, CloudSoA tgt, int blocks, hipStream_t s)
+void launch_pass_identity(const PassArgs &a, CloudSoA tgt, int blocks, bool vec4_ok, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_pass_identity, dim3(blocks), dim3(kPassThreads), 0, s, a, tgt);
+    if (vec4_ok) hipLaunchKernelGGL(k_pass_identity<4>, dim3(blocks), dim3(kPassThreads), 0, s, a, tgt);
+    else hipLaunchKernelGGL(k_pass_identity<1>, dim3(blocks), dim3(kPassThreads), 0, s, a, tgt);
 }
 
 void launch_pass_indexed(const PassArgs &a, const float4 *tq, const float4 *tn, int blocks, hipStream_t s)

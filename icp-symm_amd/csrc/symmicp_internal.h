@@ -90,7 +90,7 @@ struct PassArgs {
 };
 
 // ---- kernel launchers (kernels.hip) ---------------------------------------
-void launch_pass_identity(const PassArgs &a, CloudSoA tgt, int blocks, hipStream_t s);
+void launch_pass_identity(const PassArgs &a, CloudSoA tgt, int blocks, bool vec4_ok, hipStream_t s);
 void launch_pass_indexed(const PassArgs &a, const float4 *tq, const float4 *tn, int blocks, hipStream_t s);
 void launch_pass_tree(const PassArgs &a, const TargetIndex &ix, int blocks, hipStream_t s);
 // ev: null, or 5 events recorded before cells / after cells / after walk_wave / after walk / after accumulate
