@@ -134,8 +134,22 @@ def main():
     dom_ms = kern[dom]["avg_ms"]
     achieved = alg_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
     pass_ms = st["sum_pass_ms"] / max(1, st["passes"])
+    # HBM traffic of that kernel per launch: PMC counters cannot be read from inside this process, so they come from the
+    # committed rocprofv3 --pmc runs of this same command (profiles/r1_pmc_traffic.json, method stated there)
+    traffic = None
+    whole_pass_traffic = None
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")))
+        wk = "%s:%d:%s:%s" % (args.workload, n_s, args.mode, args.corr)
+        if world == 1 and wk in tj["workloads"]:
+            key = {"single_pass_kernel": "k_pass_identity"}.get(dom, dom)
+            traffic = tj["workloads"][wk].get(key, {}).get("hbm_bytes_per_launch")
+            whole_pass_traffic = tj["workloads"][wk].get("_whole_pass_hbm_bytes")
+    except Exception:
+        pass
     roofline = dict(bound="hbm", achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit="GB/s",
-                    frac=round(achieved / HBM_PEAK_GBS, 5), traffic=None, kernel=dom, kernel_ms=dom_ms,
+                    frac=round(achieved / HBM_PEAK_GBS, 5), traffic=traffic, whole_pass_traffic=whole_pass_traffic,
+                    kernel=dom, kernel_ms=dom_ms,
                     algorithmic_bytes_per_launch=int(alg_bytes), launches=kern[dom]["launches"],
                     whole_pass_ms=round(pass_ms, 5),
                     whole_pass_GBps=round(alg_bytes / (pass_ms * 1e-3) / 1e9, 2) if pass_ms > 0 else 0.0,
