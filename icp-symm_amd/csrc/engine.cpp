@@ -562,7 +562,8 @@ static int run_pass(symmicp_ctx *c, const float Xapply[16], bool from_cur, bool 
     a.best64 = c->best64;
     a.pos_prev = first ? nullptr : c->pos;
     a.pos_out = c->pos;
-    a.d2_out = c->d2;
+    // identity pairing streams at the HBM roof: the per-pair distances (4 B/point) are only written on request
+    a.d2_out = (c->cfg.corr == SYMMICP_CORR_IDENTITY) ? nullptr : c->d2;
     a.partials = c->partials;
     {
         const uint32_t nl = c->n_loc > 0 ? c->n_loc : 1;
@@ -790,6 +791,17 @@ int symmicp_get_correspondences(symmicp_ctx *c, int32_t *idx, float *d2, size_t 
     HIP_TRY(c, hipMemsetAsync(d_idx, 0xFF, sizeof(int32_t) * need, c->stream));
     HIP_TRY(c, hipMemsetAsync(d_d2, 0, sizeof(float) * need, c->stream));
     const int mode = c->cfg.corr == SYMMICP_CORR_IDENTITY ? 0 : (c->cfg.corr == SYMMICP_CORR_BRUTE ? 1 : 2);
+    if (mode == 0 && d2) {
+        // the identity pass streams without storing distances: evaluate them now from the current source positions
+        const bool incr = resolved_apply(c->cfg) == SYMMICP_APPLY_INCREMENTAL;
+        Affine X{};
+        float I[16];
+        identity16(I);
+        const float *m = incr ? I : c->X;
+        for (int k = 0; k < 12; k++) X.m[k] = m[k];
+        X.nrm_w = 0.f;
+        launch_identity_d2(incr ? c->cur : c->src0, X, c->tgt, c->src_off, c->n_loc, c->d2, c->stream);
+    }
     launch_corr_out(c->pos, c->best64, c->d2, c->tq, c->src_order, c->n_loc, mode, c->src_off, d_idx, d_d2, c->stream);
     if (idx) HIP_TRY(c, hipMemcpyAsync(idx, d_idx, sizeof(int32_t) * need, hipMemcpyDeviceToHost, c->stream));
     if (d2) HIP_TRY(c, hipMemcpyAsync(d2, d_d2, sizeof(float) * need, hipMemcpyDeviceToHost, c->stream));

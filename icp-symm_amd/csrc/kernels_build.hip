@@ -41,12 +41,20 @@ __global__ __launch_bounds__(256) void k_bbox(const float *__restrict__ x, const
             lo[k] = fminf(lo[k], __shfl_down(lo[k], off, 64));
             hi[k] = fmaxf(hi[k], __shfl_down(hi[k], off, 64));
         }
+    // one atomic per value per BLOCK: returning/contended atomics on a single word top out near 88 per microsecond
+    __shared__ float s_lo[4][3], s_hi[4][3];
+    const int wave = threadIdx.x >> 6;
     if ((threadIdx.x & 63) == 0) {
 #pragma unroll
-        for (int k = 0; k < 3; k++) {
-            atomicMin(bbox + k, f2ord(lo[k]));
-            atomicMax(bbox + 3 + k, f2ord(hi[k]));
-        }
+        for (int k = 0; k < 3; k++) { s_lo[wave][k] = lo[k]; s_hi[wave][k] = hi[k]; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const int k = threadIdx.x;
+        const float l = fminf(fminf(s_lo[0][k], s_lo[1][k]), fminf(s_lo[2][k], s_lo[3][k]));
+        const float h = fmaxf(fmaxf(s_hi[0][k], s_hi[1][k]), fmaxf(s_hi[2][k], s_hi[3][k]));
+        atomicMin(bbox + k, f2ord(l));
+        atomicMax(bbox + 3 + k, f2ord(h));
     }
 }
 
@@ -317,7 +325,7 @@ void launch_bbox(const float *x, const float *y, const float *z, uint32_t n, uin
     hipMemsetAsync(bbox_ord6, 0xFF, 3 * sizeof(uint32_t), s);
     hipMemsetAsync(bbox_ord6 + 3, 0x00, 3 * sizeof(uint32_t), s);
     uint32_t blocks = nblk(n, 256);
-    if (blocks > 2048) blocks = 2048;
+    if (blocks > 512) blocks = 512;
     hipLaunchKernelGGL(k_bbox, dim3(blocks), dim3(256), 0, s, x, y, z, n, bbox_ord6);
 }
 

@@ -1110,6 +1110,22 @@ __global__ __launch_bounds__(kPassThreads) void k_nn_brute(CloudSoA src, uint32_
     }
 }
 
+// per-pair squared distances of the identity pairing, on request (the streaming pass does not store them)
+__global__ __launch_bounds__(256) void k_identity_d2(CloudSoA in, Affine X, CloudSoA tgt, uint32_t tgt_offset, uint32_t n, float *d2)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float x = in.x[i], y = in.y[i], z = in.z[i];
+    const float px = xf_row(X.m + 0, x, y, z, 1.0f), py = xf_row(X.m + 4, x, y, z, 1.0f), pz = xf_row(X.m + 8, x, y, z, 1.0f);
+    const uint32_t j = tgt_offset + i;
+    d2[i] = dist2(px, py, pz, tgt.x[j], tgt.y[j], tgt.z[j]);
+}
+
+void launch_identity_d2(const CloudSoA &in, const Affine &X, const CloudSoA &tgt, uint32_t tgt_offset, uint32_t n, float *d2, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_identity_d2, dim3((n + 255) / 256), dim3(256), 0, s, in, X, tgt, tgt_offset, n, d2);
+}
+
 // ---------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------

@@ -124,6 +124,7 @@ void launch_corr_out(const int32_t *pos, const unsigned long long *best64, const
                      const uint32_t *src_order, uint32_t n, int mode, uint32_t tgt_offset, int32_t *idx_out, float *d2_out,
                      hipStream_t s);
 
+void launch_identity_d2(const CloudSoA &in, const Affine &X, const CloudSoA &tgt, uint32_t tgt_offset, uint32_t n, float *d2, hipStream_t s);
 void launch_normals_knn(const TargetIndex &ix, int k, const float vp[3], float *nrm_out, float *curv_out, hipStream_t s);
 
 }  // namespace symmicp

@@ -483,3 +483,18 @@ def test_pair_certificates_stay_exact_under_small_and_large_moves(sym, oracle):
             bad = np.nonzero(idx != ri)[0]
             assert bad.size == 0, (it, bad[:5], idx[bad[:5]], ri[bad[:5]])
             assert np.array_equal(d2, rd)
+
+
+@pytest.mark.parametrize("apply_mode", ["INCREMENTAL", "CUMULATIVE"])
+def test_identity_pairs_and_distances_on_request(sym, oracle, cat, apply_mode):
+    """identity pairing (myicp.cpp:130): rows pair up by index; the per-pair distances are evaluated on request"""
+    with sym.Engine(mode=sym.MODE_QUIRKS, corr=sym.CORR_IDENTITY, apply=getattr(sym, "APPLY_" + apply_mode), max_iters=3, fixed_iters=1) as e:
+        e.set_target(cat["tgt"], cat["tgt_n"])
+        e.set_source(cat["src"], cat["src_n"])
+        r = e.align()
+        idx, d2 = e.correspondences()
+    assert np.array_equal(idx, np.arange(3400))
+    p = oracle.apply(r["transform"], cat["src"], True)
+    ref = ((p.astype(np.float64) - cat["tgt"]) ** 2).sum(1)
+    np.testing.assert_allclose(d2, ref, rtol=2e-4)
+    assert abs(np.sqrt(d2.astype(np.float64)).sum() - r["diff_final"]) < 1e-3 * r["diff_final"]
