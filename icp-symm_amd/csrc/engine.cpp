@@ -82,6 +82,7 @@ struct symmicp_ctx {
     CloudSoA tgt{};
     float4 *tq = nullptr, *tn = nullptr;
     float4 *boxes = nullptr;
+    float4 *onodes = nullptr;
     uint2 *cells = nullptr;
     TargetIndex ix{};
     bool have_index = false;
@@ -219,8 +220,8 @@ int symmicp_create(const symmicp_config *cfg, symmicp_ctx **out)
 
 static void free_target(symmicp_ctx *c)
 {
-    hipFree(c->tgt_block); hipFree(c->tq); hipFree(c->tn); hipFree(c->boxes); hipFree(c->cells);
-    c->tgt_block = nullptr; c->tq = nullptr; c->tn = nullptr; c->boxes = nullptr; c->cells = nullptr;
+    hipFree(c->tgt_block); hipFree(c->tq); hipFree(c->tn); hipFree(c->boxes); hipFree(c->cells); hipFree(c->onodes);
+    c->tgt_block = nullptr; c->tq = nullptr; c->tn = nullptr; c->boxes = nullptr; c->cells = nullptr; c->onodes = nullptr;
     c->have_index = false; c->n_t = 0;
 }
 
@@ -338,8 +339,58 @@ static int morton_order(symmicp_ctx *c, const CloudSoA &cl, uint32_t n, uint32_t
 
 // Search index over a planar cloud: Morton sort -> float4 gather -> (optional) dense cell table at the
 // chosen octree level -> implicit 8-ary box tree.  tq/tn must already be allocated (n float4 each).
+// sparse octree over the sorted keys (levels 0..kMortonBits, built bottom-up); see TargetIndex::onodes
+static int build_octree(symmicp_ctx *c, const uint32_t *keys, const float4 *tq, uint32_t n, float4 **onodes_out, TargetIndex *ix)
+{
+    constexpr int NL = kMortonBits + 1;
+    uint32_t *nid = nullptr;                      // [NL][n]: id of the node that starts at point i, per level
+    HIP_TRY(c, hipMalloc((void **)&nid, sizeof(uint32_t) * (size_t)NL * n));
+    for (int l = 0; l < NL; l++) {
+        launch_oct_flags(keys, n, l, nid + (size_t)l * n, c->stream);
+        launch_exclusive_scan(nid + (size_t)l * n, n, c->stream);
+    }
+    // node counts: exclusive scan value at the last point, +1 if the last point starts a node (host checks the keys)
+    uint32_t last_excl[NL], kl[2] = {0, 0};
+    for (int l = 0; l < NL; l++)
+        HIP_TRY(c, hipMemcpyAsync(&last_excl[l], nid + (size_t)l * n + (n - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    if (n >= 2) HIP_TRY(c, hipMemcpyAsync(kl, keys + (n - 2), 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    uint32_t cnt[NL];
+    size_t total = 0;
+    for (int l = 0; l < NL; l++) {
+        const int shift = 3 * (kMortonBits - l);
+        const bool last_starts = (n == 1) || (shift < 30 && (kl[1] >> shift) != (kl[0] >> shift));
+        cnt[l] = last_excl[l] + (last_starts ? 1u : 0u);
+        ix->olevel_off[l] = (uint32_t)total;
+        total += cnt[l];
+    }
+    ix->olevel_off[NL] = (uint32_t)total;
+    if (total > 0xFFFFFFull * NL) { hipFree(nid); return fail(c, SYMMICP_ERR_SIZE, "octree too large"); }
+    for (int l = 0; l < NL; l++)
+        if (cnt[l] > 0xFFFFFFu) { hipFree(nid); return fail(c, SYMMICP_ERR_SIZE, "octree level exceeds 2^24 nodes"); }
+    uint32_t *first = nullptr;
+    float4 *nodes = nullptr;
+    HIP_TRY(c, hipMalloc((void **)&first, sizeof(uint32_t) * (total + 1)));
+    HIP_TRY(c, hipMalloc((void **)&nodes, sizeof(float4) * 2 * total));
+    for (int l = 0; l < NL; l++)
+        launch_oct_first(keys, n, l, nid + (size_t)l * n, first + ix->olevel_off[l], c->stream);
+    for (int l = NL - 1; l >= 0; l--) {
+        const bool bottom = (l == NL - 1);
+        launch_oct_nodes(l, tq, n, first + ix->olevel_off[l], cnt[l], bottom ? nullptr : nid + (size_t)(l + 1) * n,
+                         bottom ? 0u : cnt[l + 1], bottom ? nullptr : nodes + 2 * (size_t)ix->olevel_off[l + 1],
+                         nodes + 2 * (size_t)ix->olevel_off[l], c->stream);
+    }
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipGetLastError());
+    hipFree(nid); hipFree(first);
+    *onodes_out = nodes;
+    ix->onodes = nodes;
+    return SYMMICP_OK;
+}
+
 static int build_index(symmicp_ctx *c, const CloudSoA &cl, uint32_t n, bool want_grid, float4 *tq, float4 *tn,
-                       float4 **boxes_out, uint2 **cells_out, TargetIndex *ix_out, int32_t *glevel_out, int32_t *nlevels_out)
+                       float4 **boxes_out, uint2 **cells_out, TargetIndex *ix_out, int32_t *glevel_out, int32_t *nlevels_out,
+                       float4 **onodes_out = nullptr)
 {
     uint32_t *order = nullptr, *keys = nullptr;
     float origin[3], h0;
@@ -410,6 +461,10 @@ static int build_index(symmicp_ctx *c, const CloudSoA &cl, uint32_t n, bool want
     ix.boxes = boxes;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     HIP_TRY(c, hipGetLastError());
+    if (onodes_out) {
+        st = build_octree(c, keys, tq, n, onodes_out, &ix);
+        if (st != SYMMICP_OK) { hipFree(order); hipFree(keys); return st; }
+    }
     hipFree(order); hipFree(keys);
     *ix_out = ix;
     if (glevel_out) *glevel_out = glevel;
@@ -444,7 +499,8 @@ int symmicp_set_target(symmicp_ctx *c, const float *xyz, size_t xr, size_t xc, c
         c->st.build_ms = (now_s() - t1) * 1e3;
         return SYMMICP_OK;
     }
-    st = build_index(c, c->tgt, c->n_t, /*want_grid=*/true, c->tq, c->tn, &c->boxes, &c->cells, &c->ix, &c->st.grid_level, &c->st.tree_levels);
+    st = build_index(c, c->tgt, c->n_t, /*want_grid=*/true, c->tq, c->tn, &c->boxes, &c->cells, &c->ix, &c->st.grid_level, &c->st.tree_levels,
+                     &c->onodes);
     if (st != SYMMICP_OK) return st;
     if (std::getenv("SYMMICP_DEBUG_COUNTERS")) {
         unsigned long long *dbg = nullptr;
@@ -654,7 +710,7 @@ static int run_pass(symmicp_ctx *c, const float Xapply[16], bool from_cur, bool 
         unsigned long long h[8];
         hipMemcpy(h, c->ix.dbg, sizeof(h), hipMemcpyDeviceToHost);
         hipMemset(c->ix.dbg, 0, sizeof(h));
-        std::fprintf(stderr, "[symmicp dbg] pass %lld: walk=%llu cells=%llu loose_cells_sum=%llu\n", (long long)c->st.passes, h[0], h[1], h[2]);
+        std::fprintf(stderr, "[symmicp dbg] pass %lld: walk steps=%llu visits=%llu wave-max-steps*64=%llu\n", (long long)c->st.passes, h[3], h[4], h[5]);
     }
     std::memcpy(c->last.s, c->h_sums, sizeof(double) * kNSum);
     c->st.passes++;

@@ -315,6 +315,88 @@ __global__ __launch_bounds__(256) void k_node_boxes(const float4 *__restrict__ c
 }
 
 // ---------------------------------------------------------------------------
+// sparse octree over the sorted keys.  Level l groups points by the top 3*l key bits.
+// ---------------------------------------------------------------------------
+constexpr uint32_t kOctLeafMax = 8;
+
+__device__ __forceinline__ bool oct_is_start(const uint32_t *__restrict__ keys, uint32_t i, int shift)
+{
+    // shift == 30 (level 0) puts every point in the root
+    return i == 0 || (shift < 30 && (keys[i] >> shift) != (keys[i - 1] >> shift));
+}
+
+__global__ __launch_bounds__(256) void k_oct_flags(const uint32_t *__restrict__ keys, uint32_t n, int shift, uint32_t *nid)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) nid[i] = oct_is_start(keys, i, shift) ? 1u : 0u;
+}
+
+// after the exclusive scan nid[i] = number of node starts before i = id of the node that starts at i
+__global__ __launch_bounds__(256) void k_oct_first(const uint32_t *__restrict__ keys, uint32_t n, int shift,
+                                                   const uint32_t *__restrict__ nid, uint32_t *first)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && oct_is_start(keys, i, shift)) first[nid[i]] = i;
+}
+
+__global__ __launch_bounds__(256) void k_oct_nodes(int level, const float4 *__restrict__ tq, uint32_t n,
+                                                   const uint32_t *__restrict__ first, uint32_t n_nodes,
+                                                   const uint32_t *__restrict__ nid_next, uint32_t n_nodes_next,
+                                                   const float4 *__restrict__ nodes_next, float4 *nodes)
+{
+    const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= n_nodes) return;
+    const float inf = __int_as_float(0x7f800000);
+    const uint32_t p0 = first[id], p1 = (id + 1 < n_nodes) ? first[id + 1] : n;
+    const uint32_t npts = p1 - p0;
+    float4 lo = make_float4(inf, inf, inf, 0.f), hi = make_float4(-inf, -inf, -inf, 0.f);
+    uint32_t packed;
+    if (level == kMortonBits || npts <= kOctLeafMax) {
+        for (uint32_t j = p0; j < p1; j++) {
+            const float4 q = tq[j];
+            lo.x = fminf(lo.x, q.x); lo.y = fminf(lo.y, q.y); lo.z = fminf(lo.z, q.z);
+            hi.x = fmaxf(hi.x, q.x); hi.y = fmaxf(hi.y, q.y); hi.z = fmaxf(hi.z, q.z);
+        }
+        packed = npts & 0xFFFFFFu;                  // leaf: nchild = 0
+    } else {
+        const uint32_t c0 = nid_next[p0];
+        const uint32_t c1 = (id + 1 < n_nodes) ? nid_next[p1] : n_nodes_next;
+        for (uint32_t c = c0; c < c1; c++) {
+            const float4 a = nodes_next[2 * (size_t)c], b = nodes_next[2 * (size_t)c + 1];
+            lo.x = fminf(lo.x, a.x); lo.y = fminf(lo.y, a.y); lo.z = fminf(lo.z, a.z);
+            hi.x = fmaxf(hi.x, b.x); hi.y = fmaxf(hi.y, b.y); hi.z = fmaxf(hi.z, b.z);
+        }
+        packed = (c0 & 0xFFFFFFu) | ((c1 - c0) << 24);
+    }
+    lo.w = __int_as_float((int)p0);
+    hi.w = __int_as_float((int)packed);
+    nodes[2 * (size_t)id] = lo;
+    nodes[2 * (size_t)id + 1] = hi;
+}
+
+void launch_oct_flags(const uint32_t *keys, uint32_t n, int level, uint32_t *nid, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_oct_flags, dim3((n + 255) / 256), dim3(256), 0, s, keys, n, 3 * (kMortonBits - level), nid);
+}
+
+void launch_exclusive_scan(uint32_t *data, uint32_t n, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_rs_scan, dim3(1), dim3(1024), 0, s, data, n);
+}
+
+void launch_oct_first(const uint32_t *keys, uint32_t n, int level, const uint32_t *nid, uint32_t *first, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_oct_first, dim3((n + 255) / 256), dim3(256), 0, s, keys, n, 3 * (kMortonBits - level), nid, first);
+}
+
+void launch_oct_nodes(int level, const float4 *tq, uint32_t n, const uint32_t *first, uint32_t n_nodes, const uint32_t *nid_next,
+                      uint32_t n_nodes_next, const float4 *nodes_next, float4 *nodes, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_oct_nodes, dim3((n_nodes + 255) / 256), dim3(256), 0, s, level, tq, n, first, n_nodes, nid_next, n_nodes_next,
+                       nodes_next, nodes);
+}
+
+// ---------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------
 static inline uint32_t nblk(uint32_t n, uint32_t t) { return (n + t - 1) / t; }

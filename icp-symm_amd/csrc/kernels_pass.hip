@@ -415,6 +415,110 @@ __device__ __forceinline__ void tree_walk_nf(const TargetIndex &ix, float px, fl
 
 #undef SYMMICP_CE
 
+// ---- exact walk of the sparse octree (TargetIndex::onodes) ------------------------------------------
+// Nodes are octree cells that hold points; siblings are disjoint, so the box distance separates them at every
+// level and the first root-to-leaf descent already lands next to the answer (the run tree above needs ~30 more
+// expansions for that on a surface cloud: runs of the sorted order straddle the jumps of the Z curve and their
+// boxes overlap).  Visiting a node: a leaf scans its (<= 8, unless duplicates pile up in one finest cell) points;
+// an internal node loads its <= 8 child boxes (contiguous in the next level), enters the nearest one that can still
+// win and remembers the others as (child_first << 8 | 8-bit mask) in a register stack, one word per level.  Coming
+// back to a sibling, its box is tested again against the (now smaller) best.
+struct OctStack {
+    uint32_t s[kMortonBits];
+    __device__ __forceinline__ void push(uint32_t w)
+    {
+#pragma unroll
+        for (int k = kMortonBits - 1; k > 0; k--) s[k] = s[k - 1];
+        s[0] = w;
+    }
+    __device__ __forceinline__ void pop()
+    {
+#pragma unroll
+        for (int k = 0; k < kMortonBits - 1; k++) s[k] = s[k + 1];
+        s[kMortonBits - 1] = 0;
+    }
+};
+
+// One loop iteration = one node visit, and a leaf is visited with the SAME code as an internal node: its points
+// are read as degenerate boxes (lo = hi = point), for which boxdist2 is bit-for-bit dist2.  Lanes of a wave sit at
+// different nodes of different kinds, but now they all execute one common body (load <= 8 entities, 8 distances)
+// instead of serialising a leaf path, an internal path and a sibling path each trip.
+__device__ __forceinline__ uint32_t oct_walk(const TargetIndex &ix, float px, float py, float pz, Best &b)
+{
+    const float inf = __int_as_float(0x7f800000);
+    OctStack st;
+#pragma unroll
+    for (int k = 0; k < kMortonBits; k++) st.s[k] = 0;
+    int L = 0;
+    uint32_t idx = 0;
+    uint32_t visits = 0;
+    while (true) {
+        visits++;
+        const float4 *__restrict__ nd = ix.onodes + 2 * ((size_t)ix.olevel_off[L] + idx);
+        const uint32_t first = (uint32_t)__float_as_int(nd[0].w);
+        const uint32_t packed = (uint32_t)__float_as_int(nd[1].w);
+        const uint32_t nch = packed >> 24;
+        const bool leaf = (nch == 0);
+        const uint32_t cf = packed & 0xFFFFFFu;                 // internal: first child; leaf: number of points
+        const uint32_t total = leaf ? cf : nch;
+        // entity e of this node: leaf -> point tq[first + e] ; internal -> child box onodes[level L+1][cf + e]
+        const float4 *__restrict__ ent = leaf ? (ix.tq + first) : (ix.onodes + 2 * ((size_t)ix.olevel_off[L + 1] + cf));
+        const int stride = leaf ? 1 : 2;
+        bool descended = false;
+        for (uint32_t e0 = 0; e0 < total; e0 += 8) {           // more than one trip only for > 8 duplicates in a finest cell
+            uint32_t mask = 0;
+            int bc = 0;
+            float bd = inf;
+#pragma unroll
+            for (int h = 0; h < 8; h += 4) {
+                float4 lo[4], hi[4];
+#pragma unroll
+                for (int c = 0; c < 4; c++)
+                    if (e0 + (uint32_t)(h + c) < total) {
+                        lo[c] = ent[(e0 + h + c) * stride];
+                        hi[c] = ent[(e0 + h + c) * stride + (stride - 1)];
+                    }
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    if (e0 + (uint32_t)(h + c) < total) {
+                        const float d = boxdist2(px, py, pz, lo[c], hi[c]);
+                        if (d <= b.d2) {
+                            if (leaf) {
+                                const int row = __float_as_int(lo[c].w);
+                                if (d < b.d2 || row < b.row) { b.d2 = d; b.row = row; b.pos = (int32_t)(first + e0 + h + c); }
+                            } else {
+                                mask |= 1u << (h + c);
+                                if (d < bd) { bd = d; bc = h + c; }
+                            }
+                        }
+                    }
+                }
+            }
+            if (mask) {
+                st.push((cf << 8) | (mask & ~(1u << bc)));
+                L++;
+                idx = cf + (uint32_t)bc;
+                descended = true;
+            }
+        }
+        if (descended) continue;
+        // node done: nearest pending sibling that can still win, climbing as levels run out
+        bool found = false;
+        while (L > 0) {
+            const uint32_t w = st.s[0];
+            const uint32_t mask = w & 0xFFu;
+            if (mask == 0) { st.pop(); L--; continue; }
+            const int c = __ffs((int)mask) - 1;
+            st.s[0] = w & ~(1u << c);
+            idx = (w >> 8) + (uint32_t)c;
+            const float4 *__restrict__ sb = ix.onodes + 2 * ((size_t)ix.olevel_off[L] + idx);
+            if (boxdist2(px, py, pz, sb[0], sb[1]) <= b.d2) { found = true; break; }
+        }
+        if (!found) break;
+    }
+    return visits;
+}
+
 __device__ __forceinline__ void nn_search(const TargetIndex &ix, float px, float py, float pz, int32_t prev, Best &b)
 {
     b.d2 = __int_as_float(0x7f800000); b.pos = -1; b.row = 0x7fffffff;
@@ -829,9 +933,17 @@ __global__ __launch_bounds__(kWalkThreads) void k_search_walk(PassArgs a, Target
     Best b;
     b.pos = a.pos_out[i]; b.d2 = a.d2_out[i]; b.row = 0x7fffffff;
     if (b.pos >= 0) b.row = __float_as_int(ix.tq[b.pos].w);
-    tree_walk_nf(ix, px, py, pz, b);
+    const uint32_t sv = oct_walk(ix, px, py, pz, b);
     a.pos_out[i] = b.pos;
     a.d2_out[i] = b.d2;
+    if (ix.dbg) {
+        const uint32_t steps = sv, visits = sv;
+        uint32_t mx = steps;
+        for (int off = 32; off > 0; off >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, off, 64));
+        atomicAdd(ix.dbg + 3, (unsigned long long)steps);
+        atomicAdd(ix.dbg + 4, (unsigned long long)visits);
+        if ((threadIdx.x & 63) == 0) atomicAdd(ix.dbg + 5, (unsigned long long)mx * 64ull);
+    }
 }
 
 // ---------------------------------------------------------------------------

@@ -51,6 +51,15 @@ struct TargetIndex {
     float ox, oy, oz;        // grid origin (target bbox min)
     float h, inv_h;          // cell edge at glevel
     unsigned long long *dbg; // optional debug counters (SYMMICP_DEBUG_COUNTERS=1), else null
+    // sparse octree over the same sorted points: node = one Morton prefix (an octree cell that holds points),
+    // levels 0 (root) .. kMortonBits.  Two float4 per node:
+    //   A = (lo.x, lo.y, lo.z, first point as int bits)
+    //   B = (hi.x, hi.y, hi.z, packed)   packed = child_first (24 bits, index within the next level) | nchild << 24 ;
+    //                                     nchild == 0 marks a leaf, whose low 24 bits hold its point count
+    // Sibling cells are disjoint, so box distances discriminate at every level (unlike runs of the sorted order,
+    // whose boxes straddle the big jumps of the Z curve).
+    const float4 *onodes;
+    uint32_t olevel_off[kMortonBits + 2];
 };
 
 // Append lists for queries a kernel hands to a later kernel of the same pass.  One returning atomic on a single
@@ -115,6 +124,12 @@ void launch_gather_f4(const float *x, const float *y, const float *z, const floa
 void launch_gather_soa(const CloudSoA &src, const uint32_t *order, uint32_t n, CloudSoA dst, hipStream_t s);
 void launch_level_hist(const uint32_t *keys, uint32_t n, uint32_t *hist16, hipStream_t s);
 void launch_cell_table(const uint32_t *keys, uint32_t n, int glevel, uint2 *cells, hipStream_t s);
+// sparse octree build (levels bottom-up); see TargetIndex::onodes
+void launch_oct_flags(const uint32_t *keys, uint32_t n, int level, uint32_t *nid, hipStream_t s);
+void launch_exclusive_scan(uint32_t *data, uint32_t n, hipStream_t s);
+void launch_oct_first(const uint32_t *keys, uint32_t n, int level, const uint32_t *nid, uint32_t *first, hipStream_t s);
+void launch_oct_nodes(int level, const float4 *tq, uint32_t n, const uint32_t *first, uint32_t n_nodes, const uint32_t *nid_next,
+                      uint32_t n_nodes_next, const float4 *nodes_next, float4 *nodes, hipStream_t s);
 void launch_leaf_boxes(const float4 *tq, uint32_t n, float4 *boxes, uint32_t nleaf_padded, hipStream_t s);
 void launch_node_boxes(const float4 *child, uint32_t nchild_padded, float4 *parent, uint32_t nparent_padded, hipStream_t s);
 void launch_iota_f4(const float *x, const float *y, const float *z, const float *nx, const float *ny, const float *nz,
