@@ -344,10 +344,12 @@ static int build_octree(symmicp_ctx *c, const uint32_t *keys, const float4 *tq, 
 {
     constexpr int NL = kMortonBits + 1;
     uint32_t *nid = nullptr;                      // [NL][n]: id of the node that starts at point i, per level
+    uint32_t *scan_ws = nullptr;
     HIP_TRY(c, hipMalloc((void **)&nid, sizeof(uint32_t) * (size_t)NL * n));
+    HIP_TRY(c, hipMalloc((void **)&scan_ws, sizeof(uint32_t) * ((size_t)n / 2048 + 2)));
     for (int l = 0; l < NL; l++) {
         launch_oct_flags(keys, n, l, nid + (size_t)l * n, c->stream);
-        launch_exclusive_scan(nid + (size_t)l * n, n, c->stream);
+        launch_exclusive_scan(nid + (size_t)l * n, n, scan_ws, c->stream);
     }
     // node counts: exclusive scan value at the last point, +1 if the last point starts a node (host checks the keys)
     uint32_t last_excl[NL], kl[2] = {0, 0};
@@ -382,7 +384,7 @@ static int build_octree(symmicp_ctx *c, const uint32_t *keys, const float4 *tq, 
     }
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     HIP_TRY(c, hipGetLastError());
-    hipFree(nid); hipFree(first);
+    hipFree(nid); hipFree(first); hipFree(scan_ws);
     *onodes_out = nodes;
     ix->onodes = nodes;
     return SYMMICP_OK;

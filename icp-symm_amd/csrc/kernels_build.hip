@@ -379,9 +379,55 @@ void launch_oct_flags(const uint32_t *keys, uint32_t n, int level, uint32_t *nid
     hipLaunchKernelGGL(k_oct_flags, dim3((n + 255) / 256), dim3(256), 0, s, keys, n, 3 * (kMortonBits - level), nid);
 }
 
-void launch_exclusive_scan(uint32_t *data, uint32_t n, hipStream_t s)
+// multi-block exclusive scan: per-block scan of 2048 elements + block totals, scan of the totals, add-back
+constexpr int kScanPer = 8;
+constexpr int kScanTile = 256 * kScanPer;
+
+__global__ __launch_bounds__(256) void k_scan_tiles(uint32_t *data, uint32_t n, uint32_t *tile_sums)
 {
-    hipLaunchKernelGGL(k_rs_scan, dim3(1), dim3(1024), 0, s, data, n);
+    __shared__ uint32_t wsum[4];
+    const uint32_t base = blockIdx.x * kScanTile + threadIdx.x * kScanPer;
+    uint32_t v[kScanPer], t = 0;
+#pragma unroll
+    for (int k = 0; k < kScanPer; k++) { v[k] = (base + k < n) ? data[base + k] : 0u; t += v[k]; }
+    // inclusive scan of the per-thread totals across the block
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t incl = t;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t u = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += u;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    uint32_t wbase = 0;
+#pragma unroll
+    for (int w = 0; w < 4; w++) if (w < wave) wbase += wsum[w];
+    uint32_t run = wbase + incl - t;
+#pragma unroll
+    for (int k = 0; k < kScanPer; k++) {
+        if (base + k < n) data[base + k] = run;
+        run += v[k];
+    }
+    if (threadIdx.x == 255) tile_sums[blockIdx.x] = wbase + incl;
+}
+
+__global__ __launch_bounds__(256) void k_scan_add(uint32_t *data, uint32_t n, const uint32_t *__restrict__ tile_offsets)
+{
+    const uint32_t off = tile_offsets[blockIdx.x];
+    const uint32_t base = blockIdx.x * kScanTile + threadIdx.x * kScanPer;
+#pragma unroll
+    for (int k = 0; k < kScanPer; k++)
+        if (base + k < n) data[base + k] += off;
+}
+
+// tile_ws: at least ceil(n / 2048) words of scratch
+void launch_exclusive_scan(uint32_t *data, uint32_t n, uint32_t *tile_ws, hipStream_t s)
+{
+    const uint32_t tiles = (n + kScanTile - 1) / kScanTile;
+    hipLaunchKernelGGL(k_scan_tiles, dim3(tiles), dim3(256), 0, s, data, n, tile_ws);
+    hipLaunchKernelGGL(k_rs_scan, dim3(1), dim3(1024), 0, s, tile_ws, tiles);      // exclusive scan of the tile totals
+    hipLaunchKernelGGL(k_scan_add, dim3(tiles), dim3(256), 0, s, data, n, (const uint32_t *)tile_ws);
 }
 
 void launch_oct_first(const uint32_t *keys, uint32_t n, int level, const uint32_t *nid, uint32_t *first, hipStream_t s)

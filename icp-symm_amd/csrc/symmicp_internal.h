@@ -126,7 +126,7 @@ void launch_level_hist(const uint32_t *keys, uint32_t n, uint32_t *hist16, hipSt
 void launch_cell_table(const uint32_t *keys, uint32_t n, int glevel, uint2 *cells, hipStream_t s);
 // sparse octree build (levels bottom-up); see TargetIndex::onodes
 void launch_oct_flags(const uint32_t *keys, uint32_t n, int level, uint32_t *nid, hipStream_t s);
-void launch_exclusive_scan(uint32_t *data, uint32_t n, hipStream_t s);
+void launch_exclusive_scan(uint32_t *data, uint32_t n, uint32_t *tile_ws /* >= ceil(n/2048) words */, hipStream_t s);
 void launch_oct_first(const uint32_t *keys, uint32_t n, int level, const uint32_t *nid, uint32_t *first, hipStream_t s);
 void launch_oct_nodes(int level, const float4 *tq, uint32_t n, const uint32_t *first, uint32_t n_nodes, const uint32_t *nid_next,
                       uint32_t n_nodes_next, const float4 *nodes_next, float4 *nodes, hipStream_t s);
