@@ -455,54 +455,57 @@ __device__ __forceinline__ uint32_t oct_walk(const TargetIndex &ix, float px, fl
     while (true) {
         visits++;
         const float4 *__restrict__ nd = ix.onodes + 2 * ((size_t)ix.olevel_off[L] + idx);
-        const uint32_t first = (uint32_t)__float_as_int(nd[0].w);
-        const uint32_t packed = (uint32_t)__float_as_int(nd[1].w);
+        const float4 hA = nd[0], hB = nd[1];
+        const uint32_t first = (uint32_t)__float_as_int(hA.w);
+        const uint32_t packed = (uint32_t)__float_as_int(hB.w);
+        // the header is the node's own box: a sibling taken from the pending list is re-tested here against the
+        // current best, so the list pop below needs no loads of its own
+        const bool alive = boxdist2(px, py, pz, hA, hB) <= b.d2;
         const uint32_t nch = packed >> 24;
         const bool leaf = (nch == 0);
         const uint32_t cf = packed & 0xFFFFFFu;                 // internal: first child; leaf: number of points
-        const uint32_t total = leaf ? cf : nch;
+        const uint32_t total = alive ? (leaf ? cf : nch) : 0u;
         // entity e of this node: leaf -> point tq[first + e] ; internal -> child box onodes[level L+1][cf + e]
         const float4 *__restrict__ ent = leaf ? (ix.tq + first) : (ix.onodes + 2 * ((size_t)ix.olevel_off[L + 1] + cf));
         const int stride = leaf ? 1 : 2;
         bool descended = false;
         for (uint32_t e0 = 0; e0 < total; e0 += 8) {           // more than one trip only for > 8 duplicates in a finest cell
+            // All lanes run the same straight-line body over 8 entity slots; slots past the end re-read the last
+            // entity (harmless duplicate) instead of being predicated off.  One running arg-min serves both kinds:
+            // for a leaf it is the candidate point (ties -> lowest row), for an internal node the child to enter.
+            const uint32_t last = total - 1 - e0;               // index of the last valid slot in this group (may be >= 8)
             uint32_t mask = 0;
-            int bc = 0;
-            float bd = inf;
+            int ec = 0, erow = 0x7fffffff;
+            float ed = inf;
 #pragma unroll
             for (int h = 0; h < 8; h += 4) {
                 float4 lo[4], hi[4];
 #pragma unroll
-                for (int c = 0; c < 4; c++)
-                    if (e0 + (uint32_t)(h + c) < total) {
-                        lo[c] = ent[(e0 + h + c) * stride];
-                        hi[c] = ent[(e0 + h + c) * stride + (stride - 1)];
-                    }
+                for (int c = 0; c < 4; c++) {
+                    const uint32_t e = e0 + min((uint32_t)(h + c), last);
+                    lo[c] = ent[e * stride];
+                    hi[c] = ent[e * stride + (stride - 1)];
+                }
 #pragma unroll
                 for (int c = 0; c < 4; c++) {
-                    if (e0 + (uint32_t)(h + c) < total) {
-                        const float d = boxdist2(px, py, pz, lo[c], hi[c]);
-                        if (d <= b.d2) {
-                            if (leaf) {
-                                const int row = __float_as_int(lo[c].w);
-                                if (d < b.d2 || row < b.row) { b.d2 = d; b.row = row; b.pos = (int32_t)(first + e0 + h + c); }
-                            } else {
-                                mask |= 1u << (h + c);
-                                if (d < bd) { bd = d; bc = h + c; }
-                            }
-                        }
-                    }
+                    const float d = boxdist2(px, py, pz, lo[c], hi[c]);
+                    const int row = __float_as_int(lo[c].w);
+                    if (d <= b.d2) mask |= 1u << (h + c);
+                    if (d < ed || (d == ed && row < erow)) { ed = d; erow = row; ec = h + c; }
                 }
             }
-            if (mask) {
-                st.push((cf << 8) | (mask & ~(1u << bc)));
+            if (last < 7u) mask &= (2u << last) - 1u;           // drop the duplicate slots
+            if (leaf) {
+                if (ed <= b.d2 && (ed < b.d2 || erow < b.row)) { b.d2 = ed; b.row = erow; b.pos = (int32_t)(first + e0 + min((uint32_t)ec, last)); }
+            } else if (mask) {
+                st.push((cf << 8) | (mask & ~(1u << ec)));
                 L++;
-                idx = cf + (uint32_t)bc;
+                idx = cf + (uint32_t)ec;
                 descended = true;
             }
         }
         if (descended) continue;
-        // node done: nearest pending sibling that can still win, climbing as levels run out
+        // node done: next pending sibling, climbing as levels run out
         bool found = false;
         while (L > 0) {
             const uint32_t w = st.s[0];
@@ -511,8 +514,8 @@ __device__ __forceinline__ uint32_t oct_walk(const TargetIndex &ix, float px, fl
             const int c = __ffs((int)mask) - 1;
             st.s[0] = w & ~(1u << c);
             idx = (w >> 8) + (uint32_t)c;
-            const float4 *__restrict__ sb = ix.onodes + 2 * ((size_t)ix.olevel_off[L] + idx);
-            if (boxdist2(px, py, pz, sb[0], sb[1]) <= b.d2) { found = true; break; }
+            found = true;
+            break;
         }
         if (!found) break;
     }
