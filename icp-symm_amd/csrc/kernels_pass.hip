@@ -918,7 +918,7 @@ __global__ __launch_bounds__(kPassThreads) void k_search_cells(PassArgs a, Targe
 // one WAVE per block: walk lengths differ several-fold between regions of the cloud, and single-wave blocks let
 // the dispatcher backfill CUs at wave granularity (shorter tail than 4-wave blocks)
 constexpr int kWalkThreads = 64;
-__global__ __launch_bounds__(kWalkThreads) void k_search_walk(PassArgs a, TargetIndex ix, WorkLists wl, uint32_t kWaveModeMax)
+__global__ __launch_bounds__(kWalkThreads, 6) void k_search_walk(PassArgs a, TargetIndex ix, WorkLists wl, uint32_t kWaveModeMax)
 {
     // (a persistent variant -- waves owning list chunks, finished lanes refilling from a wave-local cursor -- was
     //  measured 1.3-2.8x SLOWER on the 1M-query first pass: the walk is latency-bound, and fewer, longer-lived waves
