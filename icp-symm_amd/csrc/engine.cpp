@@ -84,6 +84,7 @@ struct symmicp_ctx {
     float4 *boxes = nullptr;
     float4 *onodes = nullptr;
     uint2 *cells = nullptr;
+    uint32_t *ctop = nullptr;
     TargetIndex ix{};
     bool have_index = false;
     float pivot[3] = {0, 0, 0};
@@ -220,8 +221,8 @@ int symmicp_create(const symmicp_config *cfg, symmicp_ctx **out)
 
 static void free_target(symmicp_ctx *c)
 {
-    hipFree(c->tgt_block); hipFree(c->tq); hipFree(c->tn); hipFree(c->boxes); hipFree(c->cells); hipFree(c->onodes);
-    c->tgt_block = nullptr; c->tq = nullptr; c->tn = nullptr; c->boxes = nullptr; c->cells = nullptr; c->onodes = nullptr;
+    hipFree(c->tgt_block); hipFree(c->tq); hipFree(c->tn); hipFree(c->boxes); hipFree(c->cells); hipFree(c->onodes); hipFree(c->ctop);
+    c->ctop = nullptr; c->tgt_block = nullptr; c->tq = nullptr; c->tn = nullptr; c->boxes = nullptr; c->cells = nullptr; c->onodes = nullptr;
     c->have_index = false; c->n_t = 0;
 }
 
@@ -392,7 +393,7 @@ static int build_octree(symmicp_ctx *c, const uint32_t *keys, const float4 *tq, 
 
 static int build_index(symmicp_ctx *c, const CloudSoA &cl, uint32_t n, bool want_grid, float4 *tq, float4 *tn,
                        float4 **boxes_out, uint2 **cells_out, TargetIndex *ix_out, int32_t *glevel_out, int32_t *nlevels_out,
-                       float4 **onodes_out = nullptr)
+                       float4 **onodes_out = nullptr, uint32_t **ctop_out = nullptr)
 {
     uint32_t *order = nullptr, *keys = nullptr;
     float origin[3], h0;
@@ -413,7 +414,7 @@ static int build_index(symmicp_ctx *c, const CloudSoA &cl, uint32_t n, bool want
         // finest level whose occupied cells still hold >= ppc points on average
         double ppc = 2.0;
         if (const char *e = std::getenv("SYMMICP_GRID_PPC")) ppc = std::atof(e);
-        int lcap = 9;                                   // 8^9 cells x 8 B = 1 GiB
+        int lcap = kMortonBits;                          // the table is two-level: memory follows the occupied super-cells
         if (const char *e = std::getenv("SYMMICP_GRID_MAXLEVEL")) lcap = std::atoi(e);
         if (lcap > kMortonBits) lcap = kMortonBits;
         glevel = 1;
@@ -428,10 +429,29 @@ static int build_index(symmicp_ctx *c, const CloudSoA &cl, uint32_t n, bool want
     }
     ix.glevel = glevel;
     if (glevel > 0) {
-        const size_t ncell = (size_t)1 << (3 * glevel);
-        HIP_TRY(c, hipMalloc((void **)cells_out, sizeof(uint2) * ncell));
-        HIP_TRY(c, hipMemsetAsync(*cells_out, 0, sizeof(uint2) * ncell, c->stream));
-        launch_cell_table(keys, n, glevel, *cells_out, c->stream);
+        const int ltop = glevel > 3 ? glevel - 3 : 0;
+        const size_t ntop = (size_t)1 << (3 * ltop);
+        // block numbers of the occupied super-cells: exclusive scan of their start flags
+        uint32_t *nid_top = nullptr, *scan_ws = nullptr;
+        HIP_TRY(c, hipMalloc((void **)&nid_top, sizeof(uint32_t) * n));
+        HIP_TRY(c, hipMalloc((void **)&scan_ws, sizeof(uint32_t) * ((size_t)n / 2048 + 2)));
+        launch_oct_flags(keys, n, ltop, nid_top, c->stream);
+        launch_exclusive_scan(nid_top, n, scan_ws, c->stream);
+        uint32_t last_excl = 0, kl[2] = {0, 0};
+        HIP_TRY(c, hipMemcpyAsync(&last_excl, nid_top + (n - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+        if (n >= 2) HIP_TRY(c, hipMemcpyAsync(kl, keys + (n - 2), 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        const int tshift = 3 * (kMortonBits - ltop);
+        const bool last_starts = (n == 1) || (tshift < 30 && (kl[1] >> tshift) != (kl[0] >> tshift));
+        const size_t nblocks = (size_t)last_excl + (last_starts ? 1 : 0);
+        HIP_TRY(c, hipMalloc((void **)ctop_out, sizeof(uint32_t) * ntop));
+        HIP_TRY(c, hipMemsetAsync(*ctop_out, 0xFF, sizeof(uint32_t) * ntop, c->stream));
+        HIP_TRY(c, hipMalloc((void **)cells_out, sizeof(uint2) * nblocks * 512));
+        HIP_TRY(c, hipMemsetAsync(*cells_out, 0, sizeof(uint2) * nblocks * 512, c->stream));
+        launch_cell_table(keys, n, glevel, nid_top, *ctop_out, *cells_out, c->stream);
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        hipFree(nid_top); hipFree(scan_ws);
+        ix.ctop = *ctop_out;
         ix.cells = *cells_out;
         ix.gdim = 1 << glevel;
         ix.ox = origin[0]; ix.oy = origin[1]; ix.oz = origin[2];
@@ -502,7 +522,7 @@ int symmicp_set_target(symmicp_ctx *c, const float *xyz, size_t xr, size_t xc, c
         return SYMMICP_OK;
     }
     st = build_index(c, c->tgt, c->n_t, /*want_grid=*/true, c->tq, c->tn, &c->boxes, &c->cells, &c->ix, &c->st.grid_level, &c->st.tree_levels,
-                     &c->onodes);
+                     &c->onodes, &c->ctop);
     if (st != SYMMICP_OK) return st;
     if (std::getenv("SYMMICP_DEBUG_COUNTERS")) {
         unsigned long long *dbg = nullptr;

@@ -272,13 +272,19 @@ __global__ __launch_bounds__(256) void k_level_hist(const uint32_t *__restrict__
     if (threadIdx.x < 16 && h[threadIdx.x]) atomicAdd(hist16 + threadIdx.x, h[threadIdx.x]);
 }
 
-__global__ __launch_bounds__(256) void k_cell_table(const uint32_t *__restrict__ keys, uint32_t n, int shift, uint2 *cells)
+// nid_top[i] = exclusive count of super-cell (level glevel-3) starts before point i
+__global__ __launch_bounds__(256) void k_cell_table(const uint32_t *__restrict__ keys, uint32_t n, int shift, int top_shift,
+                                                    const uint32_t *__restrict__ nid_top, uint32_t *ctop, uint2 *cells)
 {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    uint32_t c = keys[i] >> shift;
-    if (i == 0 || (keys[i - 1] >> shift) != c) cells[c].x = i;
-    if (i == n - 1 || (keys[i + 1] >> shift) != c) cells[c].y = i + 1;
+    const uint32_t c = keys[i] >> shift;
+    const bool top_start = i == 0 || (top_shift < 30 && (keys[i - 1] >> top_shift) != (keys[i] >> top_shift));
+    const uint32_t block = nid_top[i] - (top_start ? 0u : 1u);
+    if (top_start) ctop[top_shift < 30 ? (keys[i] >> top_shift) : 0u] = block;
+    uint2 *slot = cells + (size_t)block * 512u + (c & 511u);
+    if (i == 0 || (keys[i - 1] >> shift) != c) slot->x = i;
+    if (i == n - 1 || (keys[i + 1] >> shift) != c) slot->y = i + 1;
 }
 
 // ---------------------------------------------------------------------------
@@ -501,10 +507,11 @@ void launch_level_hist(const uint32_t *keys, uint32_t n, uint32_t *hist16, hipSt
     hipLaunchKernelGGL(k_level_hist, dim3(blocks), dim3(256), 0, s, keys, n, hist16);
 }
 
-void launch_cell_table(const uint32_t *keys, uint32_t n, int glevel, uint2 *cells, hipStream_t s)
+void launch_cell_table(const uint32_t *keys, uint32_t n, int glevel, const uint32_t *nid_top, uint32_t *ctop, uint2 *cells, hipStream_t s)
 {
     const int shift = 3 * (kMortonBits - glevel);
-    hipLaunchKernelGGL(k_cell_table, dim3(nblk(n, 256)), dim3(256), 0, s, keys, n, shift, cells);
+    const int ltop = glevel > 3 ? glevel - 3 : 0;
+    hipLaunchKernelGGL(k_cell_table, dim3(nblk(n, 256)), dim3(256), 0, s, keys, n, shift, 3 * (kMortonBits - ltop), nid_top, ctop, cells);
 }
 
 void launch_leaf_boxes(const float4 *tq, uint32_t n, float4 *boxes, uint32_t nleaf_padded, hipStream_t s)

@@ -240,6 +240,13 @@ __global__ __launch_bounds__(kPassThreads) void k_pass_indexed(PassArgs a, const
 //            implicit 8-ary box tree ("linear BVH"), pruned by the current best.
 // Result = argmin over ALL target points of (d2, original row), identical to brute force.
 // ---------------------------------------------------------------------------
+__device__ __forceinline__ uint2 cell_range(const TargetIndex &ix, uint32_t morton)
+{
+    const uint32_t blk = ix.ctop[morton >> 9];
+    if (blk == 0xFFFFFFFFu) return make_uint2(0u, 0u);
+    return ix.cells[(size_t)blk * 512u + (morton & 511u)];
+}
+
 __device__ __forceinline__ uint32_t spread3(uint32_t v)
 {
     v &= 0x3ffu;
@@ -554,7 +561,7 @@ __device__ __forceinline__ void nn_search(const TargetIndex &ix, float px, float
                         const float gx = fmaxf(fmaxf(xlo - px, px - (xlo + ix.h)) - margin, 0.0f);
                         const float g2 = (gx * gx + gy * gy) + gz * gz;
                         if (g2 > b.d2) continue;
-                        const uint2 rng = ix.cells[mzy | spread3((uint32_t)x)];
+                        const uint2 rng = cell_range(ix, mzy | spread3((uint32_t)x));
                         for (uint32_t j = rng.x; j < rng.y; j++) test_point(b, ix.tq[j], (int32_t)j, px, py, pz);
                     }
                 }
@@ -856,7 +863,7 @@ __global__ __launch_bounds__(kPassThreads) void k_search_cells(PassArgs a, Targe
             const int kz = bit / 9, ky = (bit - 9 * kz) / 3, kx = bit - 9 * kz - 3 * ky;
             const uint32_t c0 = s_cell0[q];
             const uint32_t cx = (c0 & 1023u) + (uint32_t)kx, cy = ((c0 >> 10) & 1023u) + (uint32_t)ky, cz = (c0 >> 20) + (uint32_t)kz;
-            const uint2 rng = ix.cells[(spread3(cz) << 2) | (spread3(cy) << 1) | spread3(cx)];
+            const uint2 rng = cell_range(ix, (spread3(cz) << 2) | (spread3(cy) << 1) | spread3(cx));
             const float qx = s_px[q], qy = s_py[q], qz = s_pz[q];
             for (uint32_t j = rng.x; j < rng.y; j += 4) {
                 float4 t4[4];

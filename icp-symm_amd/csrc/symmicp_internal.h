@@ -45,7 +45,11 @@ struct TargetIndex {
     int32_t top;             // index of the top level
     uint32_t ntop;           // nodes in the top level (<= kFan)
     // grid
-    const uint2 *cells;      // [8^glevel] (first, last+1) of each Morton cell, 0/0 when empty
+    // two-level cell table: ctop[morton >> 9] = block number (or ~0 when the 8x8x8 super-cell is empty),
+    // cells[block * 512 + (morton & 511)] = (first, last+1) of the Morton cell, 0/0 when empty.
+    // Memory follows the occupied super-cells (a surface touches few), so the grid can go to level 10.
+    const uint32_t *ctop;
+    const uint2 *cells;
     int32_t glevel;          // 0 = no grid
     int32_t gdim;            // 1 << glevel
     float ox, oy, oz;        // grid origin (target bbox min)
@@ -123,7 +127,7 @@ void launch_gather_f4(const float *x, const float *y, const float *z, const floa
                       const uint32_t *order, uint32_t n, float4 *tq, float4 *tn, hipStream_t s);
 void launch_gather_soa(const CloudSoA &src, const uint32_t *order, uint32_t n, CloudSoA dst, hipStream_t s);
 void launch_level_hist(const uint32_t *keys, uint32_t n, uint32_t *hist16, hipStream_t s);
-void launch_cell_table(const uint32_t *keys, uint32_t n, int glevel, uint2 *cells, hipStream_t s);
+void launch_cell_table(const uint32_t *keys, uint32_t n, int glevel, const uint32_t *nid_top, uint32_t *ctop, uint2 *cells, hipStream_t s);
 // sparse octree build (levels bottom-up); see TargetIndex::onodes
 void launch_oct_flags(const uint32_t *keys, uint32_t n, int level, uint32_t *nid, hipStream_t s);
 void launch_exclusive_scan(uint32_t *data, uint32_t n, uint32_t *tile_ws /* >= ceil(n/2048) words */, hipStream_t s);
