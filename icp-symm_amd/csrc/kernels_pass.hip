@@ -1016,6 +1016,7 @@ __global__ __launch_bounds__(kPassThreads) void k_search_walk_wave(PassArgs a, T
         if (bpos >= 0) bkey = ((unsigned long long)__float_as_uint(bd2) << 32) | (unsigned long long)(uint32_t)__float_as_int(ix.tq[bpos].w);
         else bd2 = inf;
         float radius2 = bd2;                    // pruning radius: never below the true nearest distance
+        const float pad = kSlackFrac * ix.h;    // scan D beyond it, so the result carries a pair certificate (k_search_cells)
         bool overflowed = false;
         // top level: <= 8 nodes, lanes 0..7
         uint32_t nf = 0;
@@ -1027,7 +1028,8 @@ __global__ __launch_bounds__(kPassThreads) void k_search_walk_wave(PassArgs a, T
                 if (lo.x <= hi.x) { mind = boxdist2(px, py, pz, lo, hi); maxd = boxmaxdist2(px, py, pz, lo, hi); }
             }
             radius2 = fminf(radius2, wave_min_f32(maxd));
-            const bool keep = mind <= radius2 && mind < inf;
+            const float rp = __builtin_amdgcn_sqrtf(radius2) * 1.00001f + pad;
+            const bool keep = mind <= rp * rp * 1.00001f && mind < inf;
             const unsigned long long m = __ballot(keep);
             if (keep) fr[wave][0][__popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)lane;
             nf = (uint32_t)__popcll(m);
@@ -1048,7 +1050,8 @@ __global__ __launch_bounds__(kPassThreads) void k_search_walk_wave(PassArgs a, T
                     if (lo.x <= hi.x) { mind = boxdist2(px, py, pz, lo, hi); maxd = boxmaxdist2(px, py, pz, lo, hi); }
                 }
                 radius2 = fminf(radius2, wave_min_f32(maxd));
-                const bool keep = mind <= radius2 && mind < inf;
+                const float rp = __builtin_amdgcn_sqrtf(radius2) * 1.00001f + pad;
+                const bool keep = mind <= rp * rp * 1.00001f && mind < inf;
                 const unsigned long long m = __ballot(keep);
                 const uint32_t slot = nn + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
                 if (keep && slot < (uint32_t)kWaveFrontier) fr[wave][cur ^ 1][slot] = child;
@@ -1063,7 +1066,8 @@ __global__ __launch_bounds__(kPassThreads) void k_search_walk_wave(PassArgs a, T
             if (lane == 0) sl_push(wl.overflow, shard, i);
             continue;
         }
-        // frontier = leaves: 8 leaves x 8 points per batch
+        // frontier = leaves: 8 leaves x 8 points per batch; keep the two smallest keys seen
+        uint32_t second = 0x7f800000u;          // d2 bits of the nearest point that is not the winner
         for (uint32_t f0 = 0; f0 < nf; f0 += 8) {
             const uint32_t f = f0 + (uint32_t)(lane >> 3);
             unsigned long long key = ~0ull;
@@ -1077,11 +1081,24 @@ __global__ __launch_bounds__(kPassThreads) void k_search_walk_wave(PassArgs a, T
                 }
             }
             const unsigned long long best = wave_min_u64(key);
+            const unsigned long long runner = wave_min_u64(key == best ? ~0ull : key);
             if (best < bkey) {
+                second = min(second, min((uint32_t)(bkey >> 32), (uint32_t)(runner >> 32)));
                 bkey = best;
                 const unsigned long long who = __ballot(key == best);
                 bpos = (int32_t)__shfl((int)j, __ffsll((long long)who) - 1, 64);
+            } else if (best == bkey) {
+                second = min(second, (uint32_t)(runner >> 32));           // the previous pair found again
+            } else {
+                second = min(second, (uint32_t)(best >> 32));
             }
+        }
+        if (lane == 0 && bkey != ~0ull) {
+            // everything not scanned was pruned beyond (nearest + pad): same certificate as in k_search_cells
+            const float d1 = sqrtf(__uint_as_float((uint32_t)(bkey >> 32)));
+            const float L = fminf(sqrtf(__uint_as_float(second)), d1 + pad) * 0.99999f;
+            a.ref_x[i] = px; a.ref_y[i] = py; a.ref_z[i] = pz;
+            a.slack[i] = fmaxf(L - d1 * 1.00001f, 0.0f);
         }
         if (lane == 0) {
             a.pos_out[i] = bpos;
