@@ -110,7 +110,7 @@ struct symmicp_ctx {
     float X[16];
     symmicp_sums last{};
     // stats
-    bool timing = false;
+    int timing = 0;                  // 0 off, 1 two events per pass, 2 events around every kernel of a pass
     // timing mode: 6 events per pass in a ring of kEvRing passes, resolved lazily (no sync inside the loop)
     static constexpr int kEvRing = 64, kEvPer = 6;
     hipEvent_t ev[kEvRing * kEvPer] = {};
@@ -607,12 +607,14 @@ static void flush_events(symmicp_ctx *c)
 {
     for (int p = 0; p < c->ev_used; p++) {
         hipEvent_t *e = c->ev + p * symmicp_ctx::kEvPer;
-        if (hipEventSynchronize(e[5]) != hipSuccess) continue;
+        if (hipEventSynchronize(c->ev_split[p] == 1 ? e[4] : e[5]) != hipSuccess) continue;
         float ms = 0.f;
         double pass_ms = 0.0;
-        if (c->ev_split[p]) {
+        if (c->ev_split[p] == 2) {
             for (int k = 0; k < 5; k++)
                 if (hipEventElapsedTime(&ms, e[k], e[k + 1]) == hipSuccess) { c->st.kernel_ms[k] += ms; c->st.kernel_launches[k]++; if (k < 4) pass_ms += ms; }
+        } else if (c->ev_split[p] == 1) {
+            if (hipEventElapsedTime(&ms, e[0], e[4]) == hipSuccess) { pass_ms += ms; c->st.kernel_ms[6] += ms; c->st.kernel_launches[6]++; }
         } else {
             if (hipEventElapsedTime(&ms, e[0], e[4]) == hipSuccess) { c->st.kernel_ms[5] += ms; c->st.kernel_launches[5]++; pass_ms += ms; }
             if (hipEventElapsedTime(&ms, e[4], e[5]) == hipSuccess) { c->st.kernel_ms[4] += ms; c->st.kernel_launches[4]++; }
@@ -662,9 +664,10 @@ static int run_pass(symmicp_ctx *c, const float Xapply[16], bool from_cur, bool 
     if (c->timing) {
         if (c->ev_used == symmicp_ctx::kEvRing) flush_events(c);
         ev = c->ev + c->ev_used * symmicp_ctx::kEvPer;
-        c->ev_split[c->ev_used] = 0;
+        c->ev_split[c->ev_used] = (c->timing == 1) ? 1 : 0;
     }
-    if (ev) hipEventRecord(ev[0], c->stream);
+    // (in per-kernel mode the split launcher records ev[0] itself)
+    if (ev && !(c->timing == 2 && c->cfg.corr == SYMMICP_CORR_TREE && !std::getenv("SYMMICP_FUSED"))) hipEventRecord(ev[0], c->stream);
     switch (c->cfg.corr) {
     case SYMMICP_CORR_IDENTITY: {
         // 16-byte column loads need every planar column (length n_loc / n_t) and the shard offset to keep 16-B alignment
@@ -691,12 +694,13 @@ static int run_pass(symmicp_ctx *c, const float Xapply[16], bool from_cur, bool 
             const int nb_all = (int)((c->n_loc + kPassThreads - 1) / kPassThreads);
             int ab = nb_all < acc_cap ? ((nb_all + 7) / 8) * 8 : acc_cap;
             c->pass_blocks = blocks = ab;
-            launch_pass_tree_split(a, c->ix, c->wl, ab, c->stream, ev);
-            if (ev) c->ev_split[c->ev_used] = 1;
+            // per-kernel events only in timing mode 2; mode 1 brackets the pass (events 0 and 4)
+            launch_pass_tree_split(a, c->ix, c->wl, ab, c->stream, c->timing == 2 ? ev : nullptr);
+            if (ev && c->timing == 2) c->ev_split[c->ev_used] = 2;
         }
         break;
     }
-    if (ev && !c->ev_split[c->ev_used]) hipEventRecord(ev[4], c->stream);
+    if (ev && c->ev_split[c->ev_used] != 2) hipEventRecord(ev[4], c->stream);
     const unsigned long long seq = ++c->seq;
     volatile unsigned long long *flag = reinterpret_cast<volatile unsigned long long *>(c->h_sums + kNSum);
     launch_final_reduce(c->partials, blocks, c->d_sums, c->comm ? nullptr : c->h_sums_dev, c->ticket, seq, c->wl_count, c->stream);
@@ -705,7 +709,11 @@ static int run_pass(symmicp_ctx *c, const float Xapply[16], bool from_cur, bool 
         if (r != 0) return fail(c, SYMMICP_ERR_COMM, std::string("ncclAllReduce: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?"));
         launch_publish(c->d_sums, c->h_sums_dev, seq, c->stream);
     }
-    if (ev) { hipEventRecord(ev[5], c->stream); c->ev_used++; }
+    if (ev) {
+        // the final-reduce time is only separated out in per-kernel mode; otherwise event 5 is event 4 again
+        if (c->ev_split[c->ev_used] != 1) hipEventRecord(ev[5], c->stream);
+        c->ev_used++;
+    }
     // The record arrives in host-mapped memory followed by its sequence number: spin on that word instead of
     // paying a stream-synchronise wake-up per iteration.  A stuck stream (kernel fault) is caught by the fallback.
     g_t_launch += now_s() - t_l0;
@@ -1003,7 +1011,7 @@ int symmicp_comm_init_rank(symmicp_ctx *c, int nranks, int rank, const void *uid
 int symmicp_enable_timing(symmicp_ctx *c, int on)
 {
     if (!c) return SYMMICP_ERR_ARG;
-    c->timing = on != 0;
+    c->timing = on < 0 ? 0 : (on > 2 ? 2 : on);
     return SYMMICP_OK;
 }
 

@@ -920,42 +920,6 @@ __global__ __launch_bounds__(kPassThreads) void k_search_cells(PassArgs a, Targe
     }
 }
 
-// one thread per query.  Long work lists (far passes) come here directly; for short lists (wave mode) only
-// the overflow list of k_search_walk_wave is left.
-// one WAVE per block: walk lengths differ several-fold between regions of the cloud, and single-wave blocks let
-// the dispatcher backfill CUs at wave granularity (shorter tail than 4-wave blocks)
-constexpr int kWalkThreads = 64;
-__global__ __launch_bounds__(kWalkThreads, 6) void k_search_walk(PassArgs a, TargetIndex ix, WorkLists wl, uint32_t kWaveModeMax)
-{
-    // (a persistent variant -- waves owning list chunks, finished lanes refilling from a wave-local cursor -- was
-    //  measured 1.3-2.8x SLOWER on the 1M-query first pass: the walk is latency-bound, and fewer, longer-lived waves
-    //  hide less latency than one short-lived thread per query.)
-    __shared__ uint32_t pre[kShards + 1];
-    sl_prefix(wl.work, pre);
-    const bool wave_mode = pre[kShards] <= kWaveModeMax;      // then only the overflow list is left for this kernel
-    __syncthreads();
-    if (wave_mode) sl_prefix(wl.overflow, pre);
-    const ShardList &L = wave_mode ? wl.overflow : wl.work;
-    uint32_t i;
-    if (!sl_locate(L, pre, blockIdx.x * kWalkThreads + threadIdx.x, i)) return;
-    const float x = a.in.x[i], y = a.in.y[i], z = a.in.z[i];
-    const float px = xf_row(a.X.m + 0, x, y, z, 1.0f), py = xf_row(a.X.m + 4, x, y, z, 1.0f), pz = xf_row(a.X.m + 8, x, y, z, 1.0f);
-    Best b;
-    b.pos = a.pos_out[i]; b.d2 = a.d2_out[i]; b.row = 0x7fffffff;
-    if (b.pos >= 0) b.row = __float_as_int(ix.tq[b.pos].w);
-    const uint32_t sv = oct_walk(ix, px, py, pz, b);
-    a.pos_out[i] = b.pos;
-    a.d2_out[i] = b.d2;
-    if (ix.dbg) {
-        const uint32_t steps = sv, visits = sv;
-        uint32_t mx = steps;
-        for (int off = 32; off > 0; off >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, off, 64));
-        atomicAdd(ix.dbg + 3, (unsigned long long)steps);
-        atomicAdd(ix.dbg + 4, (unsigned long long)visits);
-        if ((threadIdx.x & 63) == 0) atomicAdd(ix.dbg + 5, (unsigned long long)mx * 64ull);
-    }
-}
-
 // ---------------------------------------------------------------------------
 // Stragglers.  In a converged pass only a few thousand queries are left on the work list (source
 // points outside the overlap: far from the target, but with a TIGHT bound from their previous pair).
@@ -994,17 +958,44 @@ __device__ __forceinline__ float wave_min_f32(float v)
     return v;
 }
 
-__global__ __launch_bounds__(kPassThreads) void k_search_walk_wave(PassArgs a, TargetIndex ix, WorkLists wl, uint32_t kWaveModeMax)
+// k_search_walk: ONE launch for both regimes of the work list (single-wave blocks: walk lengths differ several-fold
+// between regions, and single-wave blocks let the dispatcher backfill CUs at wave granularity).
+//   long list  (first pass: every query)      -> one THREAD per entry, near-first walk of the sparse octree
+//   short list (stragglers of later passes)   -> one WAVE per entry (the scheme described above), first 8192 blocks
+constexpr int kWalkThreads = 64;
+constexpr uint32_t kWaveWorkers = 8192;
+
+__global__ __launch_bounds__(kWalkThreads, 6) void k_search_walk(PassArgs a, TargetIndex ix, WorkLists wl, uint32_t kWaveModeMax)
 {
-    __shared__ uint32_t fr[kPassThreads / 64][2][kWaveFrontier];
+    __shared__ uint32_t fr[1][2][kWaveFrontier];
     __shared__ uint32_t pre[kShards + 1];
     sl_prefix(wl.work, pre);
-    if (pre[kShards] > kWaveModeMax) return;        // long list: k_search_walk does it, one thread per query
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint32_t shard = blockIdx.x & (kShards - 1);
-    const uint32_t nwaves = gridDim.x * (kPassThreads / 64);
     const float inf = __int_as_float(0x7f800000);
-    for (uint32_t w = blockIdx.x * (kPassThreads / 64) + wave; ; w += nwaves) {
+    if (pre[kShards] > kWaveModeMax) {
+        // ---- long list: one thread per entry ----
+        uint32_t i;
+        if (!sl_locate(wl.work, pre, blockIdx.x * kWalkThreads + threadIdx.x, i)) return;
+        const float x = a.in.x[i], y = a.in.y[i], z = a.in.z[i];
+        const float px = xf_row(a.X.m + 0, x, y, z, 1.0f), py = xf_row(a.X.m + 4, x, y, z, 1.0f), pz = xf_row(a.X.m + 8, x, y, z, 1.0f);
+        Best b;
+        b.pos = a.pos_out[i]; b.d2 = a.d2_out[i]; b.row = 0x7fffffff;
+        if (b.pos >= 0) b.row = __float_as_int(ix.tq[b.pos].w);
+        const uint32_t visits = oct_walk(ix, px, py, pz, b);
+        a.pos_out[i] = b.pos;
+        a.d2_out[i] = b.d2;
+        if (ix.dbg) {
+            uint32_t mx = visits;
+            for (int off = 32; off > 0; off >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, off, 64));
+            atomicAdd(ix.dbg + 4, (unsigned long long)visits);
+            if ((threadIdx.x & 63) == 0) atomicAdd(ix.dbg + 5, (unsigned long long)mx * 64ull);
+        }
+        return;
+    }
+    // ---- short list: one wave per entry ----
+    if (blockIdx.x >= kWaveWorkers) return;
+    const int lane = threadIdx.x, wave = 0;
+    const uint32_t nwaves = min(gridDim.x, kWaveWorkers);
+    for (uint32_t w = blockIdx.x; ; w += nwaves) {
         uint32_t i;
         if (!sl_locate(wl.work, pre, w, i)) break;
         const float x = a.in.x[i], y = a.in.y[i], z = a.in.z[i];
@@ -1063,7 +1054,14 @@ __global__ __launch_bounds__(kPassThreads) void k_search_walk_wave(PassArgs a, T
             __builtin_amdgcn_wave_barrier();
         }
         if (overflowed) {
-            if (lane == 0) sl_push(wl.overflow, shard, i);
+            // a frontier outgrew its LDS slot (loose bound): lane 0 finishes this one with the per-thread octree walk
+            if (lane == 0) {
+                Best b;
+                b.pos = bpos; b.d2 = bd2; b.row = (bkey == ~0ull) ? 0x7fffffff : (int32_t)(uint32_t)(bkey & 0xFFFFFFFFull);
+                oct_walk(ix, px, py, pz, b);
+                a.pos_out[i] = b.pos;
+                a.d2_out[i] = b.d2;
+            }
             continue;
         }
         // frontier = leaves: 8 leaves x 8 points per batch; keep the two smallest keys seen
@@ -1301,7 +1299,6 @@ void launch_pass_tree_split(const PassArgs &a, const TargetIndex &ix, const Work
     if (ev) hipEventRecord(ev[0], s);
     hipLaunchKernelGGL(k_search_cells, dim3(nbp), dim3(kPassThreads), 0, s, a, ix, wl);
     if (ev) hipEventRecord(ev[1], s);
-    hipLaunchKernelGGL(k_search_walk_wave, dim3(2048), dim3(kPassThreads), 0, s, a, ix, wl, wave_mode_max);
     if (ev) hipEventRecord(ev[2], s);
     const uint32_t list_blocks = kShards * (wl.work.cap / kWalkThreads);      // enough blocks for one thread per list entry
     hipLaunchKernelGGL(k_search_walk, dim3(list_blocks), dim3(kWalkThreads), 0, s, a, ix, wl, wave_mode_max);

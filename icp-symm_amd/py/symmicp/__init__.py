@@ -62,7 +62,7 @@ class Stats(C.Structure):
                 ("kernel_ms", C.c_double * 8), ("kernel_launches", C.c_int64 * 8)]
 
 
-KERNEL_SLOTS = ["k_search_cells", "k_search_walk_wave", "k_search_walk", "k_accumulate", "k_final_reduce", "single_pass_kernel"]
+KERNEL_SLOTS = ["k_search_cells", "(gap)", "k_search_walk", "k_accumulate", "k_final_reduce", "single_pass_kernel", "whole_pass"]
 
 
 # every symbol include/symmicp.h declares (checked by tests/test_abi.py)
@@ -361,7 +361,7 @@ class Engine:
         return xyz, nrm
 
     def enable_timing(self, on=True):
-        self._chk(self._L.symmicp_enable_timing(self._h, int(on)))
+        self._chk(self._L.symmicp_enable_timing(self._h, int(on)))      # 0 off, 1 per pass, 2 per kernel
 
     def reset_stats(self):
         self._chk(self._L.symmicp_reset_stats(self._h))

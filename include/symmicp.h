@@ -184,13 +184,16 @@ typedef struct {
     int64_t bytes_algorithmic_per_pass;  /* N_s*(48+4+4)+N_t*12 (NN) or N_s*48 (identity) [+24 N_s write-back] */
     /* per-kernel HIP-event time since the last reset (timing mode), slots:
      * 0 k_search_cells, 1 k_search_walk_wave, 2 k_search_walk, 3 k_accumulate, 4 k_final_reduce,
-     * 5 the single pass kernel of the IDENTITY / BRUTE modes (k_pass_identity, or k_nn_brute + k_pass_indexed) */
+     * 5 the single pass kernel of the IDENTITY / BRUTE modes (k_pass_identity, or k_nn_brute + k_pass_indexed),
+     * 6 the whole pass bracketed by two events (timing mode 1) */
     double kernel_ms[8];
     int64_t kernel_launches[8];
 } symmicp_stats;
 int symmicp_get_stats(symmicp_ctx *ctx, symmicp_stats *out);
 int symmicp_reset_stats(symmicp_ctx *ctx);
-int symmicp_enable_timing(symmicp_ctx *ctx, int on);   /* record HIP events around each kernel of a pass (on the ctx stream) */
+/* HIP events on the ctx stream: 0 off, 1 two events bracketing each pass, 2 events around every kernel of a pass
+ * (each record costs a few microseconds of GPU timeline: mode 2 is for profiling, not for throughput runs) */
+int symmicp_enable_timing(symmicp_ctx *ctx, int on);
 
 /* ---- PCD I/O (replaces pcl::PCDReader use in MyICP::LoadCloud, myicp.cpp:20-31) */
 /* returns point count (>=0) or -symmicp_status.  xyz/nrm packed AoS (3 floats per point); pass
