@@ -8,6 +8,7 @@
 //   k_leaf_boxes / k_node_boxes   tight boxes of the implicit 8-ary tree (linear BVH)
 // These replace nothing in the reference (it has no search structure: myicp.cpp:128-131
 // is a todo); they are the SURVEY 8(a) k_morton / k_radix_sort / k_cell_ranges rows.
+#include <cstdlib>
 #include "symmicp_internal.h"
 #pragma clang fp contract(off)
 
@@ -323,7 +324,6 @@ __global__ __launch_bounds__(256) void k_node_boxes(const float4 *__restrict__ c
 // ---------------------------------------------------------------------------
 // sparse octree over the sorted keys.  Level l groups points by the top 3*l key bits.
 // ---------------------------------------------------------------------------
-constexpr uint32_t kOctLeafMax = 8;
 
 __device__ __forceinline__ bool oct_is_start(const uint32_t *__restrict__ keys, uint32_t i, int shift)
 {
@@ -348,7 +348,7 @@ __global__ __launch_bounds__(256) void k_oct_first(const uint32_t *__restrict__ 
 __global__ __launch_bounds__(256) void k_oct_nodes(int level, const float4 *__restrict__ tq, uint32_t n,
                                                    const uint32_t *__restrict__ first, uint32_t n_nodes,
                                                    const uint32_t *__restrict__ nid_next, uint32_t n_nodes_next,
-                                                   const float4 *__restrict__ nodes_next, float4 *nodes)
+                                                   const float4 *__restrict__ nodes_next, float4 *nodes, uint32_t kOctLeafMax)
 {
     const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
     if (id >= n_nodes) return;
@@ -444,8 +444,10 @@ void launch_oct_first(const uint32_t *keys, uint32_t n, int level, const uint32_
 void launch_oct_nodes(int level, const float4 *tq, uint32_t n, const uint32_t *first, uint32_t n_nodes, const uint32_t *nid_next,
                       uint32_t n_nodes_next, const float4 *nodes_next, float4 *nodes, hipStream_t s)
 {
+    // a cell with at most this many points is a leaf (the walk tests 8 entities per trip)
+    static const uint32_t leaf_max = getenv("SYMMICP_OCT_LEAF") ? (uint32_t)atoi(getenv("SYMMICP_OCT_LEAF")) : 8u;
     hipLaunchKernelGGL(k_oct_nodes, dim3((n_nodes + 255) / 256), dim3(256), 0, s, level, tq, n, first, n_nodes, nid_next, n_nodes_next,
-                       nodes_next, nodes);
+                       nodes_next, nodes, leaf_max);
 }
 
 // ---------------------------------------------------------------------------
