@@ -667,7 +667,7 @@ static int run_pass(symmicp_ctx *c, const float Xapply[16], bool from_cur, bool 
         c->ev_split[c->ev_used] = (c->timing == 1) ? 1 : 0;
     }
     // (in per-kernel mode the split launcher records ev[0] itself)
-    if (ev && !(c->timing == 2 && c->cfg.corr == SYMMICP_CORR_TREE && !std::getenv("SYMMICP_FUSED"))) hipEventRecord(ev[0], c->stream);
+    if (ev && !(c->timing == 2 && c->cfg.corr == SYMMICP_CORR_TREE)) hipEventRecord(ev[0], c->stream);
     switch (c->cfg.corr) {
     case SYMMICP_CORR_IDENTITY: {
         // 16-byte column loads need every planar column (length n_loc / n_t) and the shard offset to keep 16-B alignment
@@ -686,9 +686,7 @@ static int run_pass(symmicp_ctx *c, const float Xapply[16], bool from_cur, bool 
         launch_pass_indexed(a, c->tq, c->tn, blocks, c->stream);
         break;
     default:
-        if (std::getenv("SYMMICP_FUSED")) {
-            launch_pass_tree(a, c->ix, blocks, c->stream);
-        } else {
+        {
             // the accumulate kernel is streaming: 8 blocks per CU worth of grid, a multiple of 8 for the XCD remap
             static const int acc_cap = std::getenv("SYMMICP_ACC_BLOCKS") ? std::atoi(std::getenv("SYMMICP_ACC_BLOCKS")) : 2048;
             const int nb_all = (int)((c->n_loc + kPassThreads - 1) / kPassThreads);

@@ -1,12 +1,13 @@
 // kernels_pass.hip -- the per-iteration kernels of the symmetric-ICP loop for gfx950.
 //
 // One "pass" = everything the reference does per trip of myicp.cpp:123-142 that
-// touches all N points, fused into a single sweep over the source share:
+// touches all N points.  Identity pairing is one streaming kernel; the nearest-neighbour
+// pass is k_search_cells -> k_search_walk -> k_accumulate (see below).  Per point:
 //   applyTransform (func.cpp:104-121)  -> transform p, n_p on the fly (optionally write back)
-//   correspondence (myicp.cpp:128-131) -> identity / precomputed / fused exact NN search
+//   correspondence (myicp.cpp:128-131) -> identity / brute force / exact NN through cell table + trees
 //   calculateMatrixNotation (func.cpp:43-60) -> M_i, N_i, c_i in fp32 registers, never stored
 //   the O(N) parts of solveLLS / means / evalDiff (func.cpp:19-32,64-73,85)
-//                                     -> 37 fp64 sums per thread -> wave64 shuffle tree
+//                                     -> 37 fp64 sums per thread -> wave64 DPP sum
 //                                        -> LDS across the 4 waves -> one record per block.
 // The path is HBM/L2-bound integer+fp32 work; no MFMA.
 //
@@ -272,155 +273,6 @@ __device__ __forceinline__ void test_point(Best &b, const float4 &q, int32_t pos
     }
 }
 
-__device__ __forceinline__ void scan_leaf(const TargetIndex &ix, uint32_t leaf, float px, float py, float pz, Best &b)
-{
-    const uint32_t j0 = leaf * kLeaf;
-    if (j0 + kLeaf <= ix.n) {
-        float4 q[kLeaf];
-#pragma unroll
-        for (int k = 0; k < kLeaf; k++) q[k] = ix.tq[j0 + k];      // 128 B, one line: all loads in flight together
-#pragma unroll
-        for (int k = 0; k < kLeaf; k++) test_point(b, q[k], (int32_t)(j0 + k), px, py, pz);
-    } else {
-        for (uint32_t j = j0; j < ix.n; j++) test_point(b, ix.tq[j], (int32_t)j, px, py, pz);
-    }
-}
-
-// ---- near-first exact walk of the implicit 8-ary box tree -----------------------------------------
-// Node (L, i) has children (L-1, 8i+c).  Expanding a node loads its 8 child boxes together (256 B
-// contiguous), keeps the children whose box is not farther than the current best, and SORTS them by
-// box distance with a 19-comparator network on packed keys (distance bits with the low 3 bits replaced
-// by the child number).  The nearest child is entered first; the order of the remaining ones is kept
-// as a list of 4-bit child numbers in one register per level (a register "stack" of at most 8 levels,
-// shifted on push/pop: no scratch, no LDS).  When the walk comes back to a sibling its box is tested
-// again against the (now smaller) best, and because the list is sorted the first box that is too far
-// ends the whole level.  The first root-to-leaf descent therefore finds a near-optimal candidate and
-// everything after it is pruned hard.
-constexpr uint32_t kListEmpty = 0xFFFFFFFFu;
-
-struct ListStack {
-    uint32_t s[8];
-    __device__ __forceinline__ void push(uint32_t w)
-    {
-#pragma unroll
-        for (int k = 7; k > 0; k--) s[k] = s[k - 1];
-        s[0] = w;
-    }
-    __device__ __forceinline__ void pop()
-    {
-#pragma unroll
-        for (int k = 0; k < 7; k++) s[k] = s[k + 1];
-        s[7] = kListEmpty;
-    }
-};
-
-#define SYMMICP_CE(a, b) { const uint32_t lo_ = min(k[a], k[b]); const uint32_t hi_ = max(k[a], k[b]); k[a] = lo_; k[b] = hi_; }
-
-// sorted keys of the children of one node that can still hold something not farther than `best`
-__device__ __forceinline__ void sorted_child_keys(const float4 *__restrict__ bx, int nchild, float px, float py, float pz,
-                                                  float best, uint32_t k[kFan])
-{
-    // two halves of four children: 8 loads in flight at a time keeps the register peak (and with it the
-    // occupancy of the latency-bound walk) in check
-#pragma unroll
-    for (int h = 0; h < kFan; h += 4) {
-        float4 lo[4], hi[4];
-#pragma unroll
-        for (int c = 0; c < 4; c++)
-            if (h + c < nchild) { lo[c] = bx[2 * (h + c)]; hi[c] = bx[2 * (h + c) + 1]; }
-#pragma unroll
-        for (int c = 0; c < 4; c++) {
-            k[h + c] = kListEmpty;
-            if (h + c < nchild && lo[c].x <= hi[c].x) {
-                const float d = boxdist2(px, py, pz, lo[c], hi[c]);
-                if (d <= best) k[h + c] = (__float_as_uint(d) & ~7u) | (uint32_t)(h + c);
-            }
-        }
-    }
-    SYMMICP_CE(0, 2) SYMMICP_CE(1, 3) SYMMICP_CE(4, 6) SYMMICP_CE(5, 7)
-    SYMMICP_CE(0, 4) SYMMICP_CE(1, 5) SYMMICP_CE(2, 6) SYMMICP_CE(3, 7)
-    SYMMICP_CE(0, 1) SYMMICP_CE(2, 3) SYMMICP_CE(4, 5) SYMMICP_CE(6, 7)
-    SYMMICP_CE(2, 4) SYMMICP_CE(3, 5)
-    SYMMICP_CE(1, 4) SYMMICP_CE(3, 6)
-    SYMMICP_CE(1, 2) SYMMICP_CE(3, 4) SYMMICP_CE(5, 6)
-}
-
-// one step of the walk for one query: at most one node expansion (or leaf-parent scan) followed by at most one
-// sibling advance / climb.  Returns true when the walk is complete.
-__device__ __forceinline__ bool walk_step(const TargetIndex &ix, float px, float py, float pz, Best &b, int &L, uint32_t &i,
-                                          bool &expand, ListStack &st)
-{
-    if (expand) {
-        const int cl = L - 1;
-        const uint32_t cbase = i << 3;
-        uint32_t k[kFan];
-        sorted_child_keys(ix.boxes + 2 * ((size_t)ix.level_off[cl] + cbase), (L == ix.top + 1) ? (int)ix.ntop : kFan,
-                          px, py, pz, b.d2, k);
-        if (cl == 0) {
-            // children are leaves: scan them nearest first; a sorted key already beyond best ends the node
-#pragma unroll
-            for (int q = 0; q < kFan; q++) {
-                if (k[q] == kListEmpty) break;
-                if (__uint_as_float(k[q] & ~7u) > b.d2) break;
-                scan_leaf(ix, cbase + (k[q] & 7u), px, py, pz, b);
-            }
-            // node (L, i) finished
-        } else if (k[0] != kListEmpty) {
-            uint32_t w = 0;
-#pragma unroll
-            for (int q = 1; q < kFan; q++) w |= ((k[q] == kListEmpty) ? 0xFu : (k[q] & 7u)) << (4 * (q - 1));
-            w |= 0xF0000000u;
-            st.push(w);                      // remaining children of (L, i), nearest first
-            L = cl;
-            i = cbase + (k[0] & 7u);
-            return false;                    // next step expands the nearest child
-        }
-    }
-    // (L, i) is finished: next sibling from the list of level L, else climb
-    if (L > ix.top) return true;
-    const uint32_t w = st.s[0];
-    const uint32_t c = w & 0xFu;
-    if (c == 0xFu) {                         // level exhausted -> parent finished
-        st.pop();
-        i >>= 3;
-        L++;
-        expand = false;
-        return false;
-    }
-    st.s[0] = (w >> 4) | 0xF0000000u;
-    const uint32_t sib = (i & ~7u) | c;
-    const float4 *__restrict__ bx = ix.boxes + 2 * ((size_t)ix.level_off[L] + sib);
-    const float d = boxdist2(px, py, pz, bx[0], bx[1]);
-    if (__uint_as_float(__float_as_uint(d) & ~7u) > b.d2) {
-        st.s[0] = kListEmpty;                // sorted: everything after it is at least as far
-        expand = false;
-        return false;
-    }
-    i = sib;
-    expand = (d <= b.d2);                    // within 8 ulp of best but beyond it: skip just this one
-    return false;
-}
-
-__device__ __forceinline__ void walk_init(const TargetIndex &ix, int &L, uint32_t &i, bool &expand, ListStack &st)
-{
-#pragma unroll
-    for (int q = 0; q < 8; q++) st.s[q] = kListEmpty;
-    L = ix.top + 1;                // virtual root above the top level
-    i = 0;
-    expand = true;
-}
-
-__device__ __forceinline__ void tree_walk_nf(const TargetIndex &ix, float px, float py, float pz, Best &b)
-{
-    ListStack st;
-    int L;
-    uint32_t i;
-    bool expand;
-    walk_init(ix, L, i, expand, st);
-    while (!walk_step(ix, px, py, pz, b, L, i, expand, st)) {}
-}
-
-#undef SYMMICP_CE
 
 // ---- exact walk of the sparse octree (TargetIndex::onodes) ------------------------------------------
 // Nodes are octree cells that hold points; siblings are disjoint, so the box distance separates them at every
@@ -495,10 +347,15 @@ __device__ __forceinline__ uint32_t oct_walk(const TargetIndex &ix, float px, fl
                 }
 #pragma unroll
                 for (int c = 0; c < 4; c++) {
+                    // branch-free on purpose (selects, not jumps): eight tiny divergent branches per visit cost more
+                    // scalar/exec bookkeeping than the work they skip
                     const float d = boxdist2(px, py, pz, lo[c], hi[c]);
                     const int row = __float_as_int(lo[c].w);
-                    if (d <= b.d2) mask |= 1u << (h + c);
-                    if (d < ed || (d == ed && row < erow)) { ed = d; erow = row; ec = h + c; }
+                    mask |= (d <= b.d2) ? (1u << (h + c)) : 0u;
+                    const bool better = (d < ed) | ((d == ed) & (row < erow));
+                    ed = better ? d : ed;
+                    erow = better ? row : erow;
+                    ec = better ? (h + c) : ec;
                 }
             }
             if (last < 7u) mask &= (2u << last) - 1u;           // drop the duplicate slots
@@ -529,100 +386,17 @@ __device__ __forceinline__ uint32_t oct_walk(const TargetIndex &ix, float px, fl
     return visits;
 }
 
-__device__ __forceinline__ void nn_search(const TargetIndex &ix, float px, float py, float pz, int32_t prev, Best &b)
-{
-    b.d2 = __int_as_float(0x7f800000); b.pos = -1; b.row = 0x7fffffff;
-    // phase 0: the pair of the previous pass, if any, is a real candidate (temporal coherence)
-    if (prev >= 0 && (uint32_t)prev < ix.n) test_point(b, ix.tq[prev], prev, px, py, pz);
-    // phase 1: every target point not farther than the candidate lies in the ball around the query;
-    // if that ball overlaps at most 3 cells per axis of the dense Morton cell table, scan those cells.
-    if (b.pos >= 0 && ix.glevel > 0) {
-        const float margin = 2e-3f * ix.h;         // cell assignment is fp32: stay conservative
-        const float gmax = (float)ix.gdim;
-        const float r = sqrtf(b.d2) * 1.000001f + margin;
-        const float lx = (px - r - ix.ox) * ix.inv_h, hx = (px + r - ix.ox) * ix.inv_h;
-        const float ly = (py - r - ix.oy) * ix.inv_h, hy = (py + r - ix.oy) * ix.inv_h;
-        const float lz = (pz - r - ix.oz) * ix.inv_h, hz = (pz + r - ix.oz) * ix.inv_h;
-        // clamp in float first (keeps the int conversion defined for huge values)
-        const int x0 = (int)floorf(fminf(fmaxf(lx, 0.0f), gmax - 1.0f)), x1 = (int)floorf(fminf(fmaxf(hx, 0.0f), gmax - 1.0f));
-        const int y0 = (int)floorf(fminf(fmaxf(ly, 0.0f), gmax - 1.0f)), y1 = (int)floorf(fminf(fmaxf(hy, 0.0f), gmax - 1.0f));
-        const int z0 = (int)floorf(fminf(fmaxf(lz, 0.0f), gmax - 1.0f)), z1 = (int)floorf(fminf(fmaxf(hz, 0.0f), gmax - 1.0f));
-        if (x1 - x0 <= 2 && y1 - y0 <= 2 && z1 - z0 <= 2) {
-            for (int z = z0; z <= z1; z++) {
-                const float zlo = ix.oz + (float)z * ix.h;
-                const float gz = fmaxf(fmaxf(zlo - pz, pz - (zlo + ix.h)) - margin, 0.0f);
-                const uint32_t mz = spread3((uint32_t)z) << 2;
-                for (int y = y0; y <= y1; y++) {
-                    const float ylo = ix.oy + (float)y * ix.h;
-                    const float gy = fmaxf(fmaxf(ylo - py, py - (ylo + ix.h)) - margin, 0.0f);
-                    const uint32_t mzy = mz | (spread3((uint32_t)y) << 1);
-                    for (int x = x0; x <= x1; x++) {
-                        const float xlo = ix.ox + (float)x * ix.h;
-                        const float gx = fmaxf(fmaxf(xlo - px, px - (xlo + ix.h)) - margin, 0.0f);
-                        const float g2 = (gx * gx + gy * gy) + gz * gz;
-                        if (g2 > b.d2) continue;
-                        const uint2 rng = cell_range(ix, mzy | spread3((uint32_t)x));
-                        for (uint32_t j = rng.x; j < rng.y; j++) test_point(b, ix.tq[j], (int32_t)j, px, py, pz);
-                    }
-                }
-            }
-            if (ix.dbg) atomicAdd(ix.dbg + 1, 1ull);
-            return;
-        }
-        if (ix.dbg) atomicAdd(ix.dbg + 2, (unsigned long long)(x1 - x0 + 1) * (y1 - y0 + 1) * (z1 - z0 + 1));
-    }
-    // phase 2: no candidate, or a loose one -> near-first tree walk (exact for any bound)
-    if (ix.dbg) atomicAdd(ix.dbg + 0, 1ull);
-    tree_walk_nf(ix, px, py, pz, b);
-}
-
-// Two sweeps over this thread's points inside ONE launch: sweep A searches (registers: walk state),
-// sweep B accumulates (registers: 37 fp64 sums).  Keeping them apart lets the two register sets
-// overlap instead of adding up, which is worth one more wave per SIMD.
-__global__ __launch_bounds__(kPassThreads) void k_pass_tree(PassArgs a, TargetIndex ix)
-{
-    const uint32_t stride = gridDim.x * blockDim.x;
-    const uint32_t first = blockIdx.x * blockDim.x + threadIdx.x;
-    for (uint32_t i = first; i < a.n; i += stride) {
-        const float x = a.in.x[i], y = a.in.y[i], z = a.in.z[i];
-        const float px = xf_row(a.X.m + 0, x, y, z, 1.0f), py = xf_row(a.X.m + 4, x, y, z, 1.0f), pz = xf_row(a.X.m + 8, x, y, z, 1.0f);
-        Best b;
-        nn_search(ix, px, py, pz, a.pos_prev ? a.pos_prev[i] : -1, b);
-        a.pos_out[i] = b.pos;
-        a.d2_out[i] = b.d2;
-    }
-    Acc acc; acc_zero(acc);
-    for (uint32_t i = first; i < a.n; i += stride) {
-        const float x = a.in.x[i], y = a.in.y[i], z = a.in.z[i];
-        const float nx = a.in.nx[i], ny = a.in.ny[i], nz = a.in.nz[i];
-        const float px = xf_row(a.X.m + 0, x, y, z, 1.0f), py = xf_row(a.X.m + 4, x, y, z, 1.0f), pz = xf_row(a.X.m + 8, x, y, z, 1.0f);
-        const float npx = xf_row(a.X.m + 0, nx, ny, nz, a.X.nrm_w), npy = xf_row(a.X.m + 4, nx, ny, nz, a.X.nrm_w),
-                    npz = xf_row(a.X.m + 8, nx, ny, nz, a.X.nrm_w);
-        if (a.writeback) {
-            a.out.x[i] = px; a.out.y[i] = py; a.out.z[i] = pz;
-            a.out.nx[i] = npx; a.out.ny[i] = npy; a.out.nz[i] = npz;
-        }
-        const int32_t pos = a.pos_out[i];          // written by this same thread in sweep A
-        const float d2 = a.d2_out[i];
-        if (pos < 0) continue;
-        if (a.max_d2 > 0.0f && d2 > a.max_d2) continue;
-        const float4 q = ix.tq[pos], nq = ix.tn[pos];
-        acc_pair(acc, px, py, pz, npx, npy, npz, q.x, q.y, q.z, nq.x, nq.y, nq.z, d2, a.pivot);
-    }
-    acc_block_reduce_store(acc, a.partials, gridDim.x);
-}
-
 // ---------------------------------------------------------------------------
-// The same pass as three lean kernels (default for TREE correspondences):
-//   k_search_fast  1 point per thread: transform, previous-pair bound, cell scan.  ~40 VGPRs -> 8 waves
-//                  per SIMD to hide the dependent gathers.  Queries it cannot finish (no previous pair,
-//                  or a ball wider than 3 cells) go to a work list.
-//   k_search_walk  near-first tree walk for the work list only (compacted: every lane is a walker).
-//   k_accumulate   streaming: rows + 37 fp64 sums from the stored pairs (and the optional write-back).
-// Blocks are dealt to XCDs round-robin, so block b is remapped to a contiguous chunk of the Morton-
-// sorted source per XCD: each XCD's 4 MB L2 then serves one compact region of the target.
+// The nearest-neighbour pass (SYMMICP_CORR_TREE) is three kernels plus the final reduce:
+//   k_search_cells  thread = query: pair certificate / cell scan / 27-cell probe; what it cannot finish goes to a
+//                   work list (64-shard append list)
+//   k_search_walk   the work list: one thread per entry on the sparse octree (long lists: the first pass), or one
+//                   wave per entry on the run tree (short lists: stragglers)
+//   k_accumulate    streaming: rows + 37 fp64 sums from the stored pairs (and the optional write-back)
+// Blocks are dealt to XCDs round-robin, so block b is remapped to a contiguous chunk of the Morton-sorted source
+// per XCD: each XCD's 4 MB L2 then serves one compact region of the target.
 // ---------------------------------------------------------------------------
-constexpr int kWaveFrontier = 512;        // nodes per level per wave (k_search_walk_wave)
+constexpr int kWaveFrontier = 512;        // frontier nodes per level in the wave-per-entry walk
 
 __device__ __forceinline__ void sl_push(const ShardList &L, uint32_t shard, uint32_t v)
 {
@@ -657,13 +431,6 @@ __device__ __forceinline__ bool sl_locate(const ShardList &L, const uint32_t *pr
         if (pre[lo + step] <= g) lo += step;
     item = L.items[(size_t)lo * L.cap + (g - pre[lo])];
     return true;
-}
-
-__device__ __forceinline__ uint32_t sl_total(const ShardList &L)
-{
-    uint32_t t = 0;
-    for (int sh = 0; sh < kShards; sh++) t += L.counts[sh * kShardStride];
-    return t;
 }
 
 __device__ __forceinline__ uint32_t xcd_remap(uint32_t b, uint32_t nb_padded)
@@ -1275,11 +1042,6 @@ void launch_pass_identity(const PassArgs &a, CloudSoA tgt, int blocks, bool vec4
 void launch_pass_indexed(const PassArgs &a, const float4 *tq, const float4 *tn, int blocks, hipStream_t s)
 {
     hipLaunchKernelGGL(k_pass_indexed, dim3(blocks), dim3(kPassThreads), 0, s, a, tq, tn);
-}
-
-void launch_pass_tree(const PassArgs &a, const TargetIndex &ix, int blocks, hipStream_t s)
-{
-    hipLaunchKernelGGL(k_pass_tree, dim3(blocks), dim3(kPassThreads), 0, s, a, ix);
 }
 
 uint32_t shard_capacity(uint32_t n_points)

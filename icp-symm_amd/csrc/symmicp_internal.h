@@ -105,7 +105,6 @@ struct PassArgs {
 // ---- kernel launchers (kernels.hip) ---------------------------------------
 void launch_pass_identity(const PassArgs &a, CloudSoA tgt, int blocks, bool vec4_ok, hipStream_t s);
 void launch_pass_indexed(const PassArgs &a, const float4 *tq, const float4 *tn, int blocks, hipStream_t s);
-void launch_pass_tree(const PassArgs &a, const TargetIndex &ix, int blocks, hipStream_t s);
 // ev: null, or 5 events recorded before cells / after cells / after walk_wave / after walk / after accumulate
 void launch_pass_tree_split(const PassArgs &a, const TargetIndex &ix, const WorkLists &wl, int acc_blocks, hipStream_t s, hipEvent_t *ev);
 uint32_t shard_capacity(uint32_t n_points);
