@@ -172,6 +172,9 @@ void symmicp_config_default(symmicp_config *cfg)
     cfg->fixed_iters = 0;
     cfg->sort_source = 1;
     cfg->verbose = 0;
+    cfg->min_normal_dot = -2.0f;
+    cfg->eps_rotation = 0.f;
+    cfg->eps_translation = 0.f;
 }
 
 static int check_cfg(const symmicp_config *cfg)
@@ -638,6 +641,7 @@ static int run_pass(symmicp_ctx *c, const float Xapply[16], bool from_cur, bool 
     const bool paper = c->cfg.mode == SYMMICP_MODE_PAPER;
     for (int k = 0; k < 3; k++) a.pivot[k] = paper ? c->pivot[k] : 0.0f;
     a.max_d2 = c->cfg.max_corr_dist > 0.f ? c->cfg.max_corr_dist * c->cfg.max_corr_dist : 0.f;
+    a.min_ndot = c->cfg.min_normal_dot;
     a.writeback = writeback ? 1 : 0;
     a.best64 = c->best64;
     a.pos_prev = first ? nullptr : c->pos;
@@ -823,6 +827,14 @@ int symmicp_align(symmicp_ctx *c, const float *guess16, symmicp_result *out)
         st = symmicp_step(c, &it);
         if (st != SYMMICP_OK) { iters--; break; }
         diff = it.diff;                                             // myicp.cpp:141
+        if (c->cfg.eps_rotation > 0.f && c->cfg.eps_translation > 0.f && !c->cfg.fixed_iters) {
+            // convergence on the increment (the reference only has the diff threshold, myicp.cpp:123)
+            const float *Xi = it.increment;
+            const double tr = ((double)Xi[0] + Xi[5] + Xi[10] - 1.0) * 0.5;
+            const double ang = std::acos(tr > 1.0 ? 1.0 : (tr < -1.0 ? -1.0 : tr));
+            const double tn = std::sqrt((double)Xi[3] * Xi[3] + (double)Xi[7] * Xi[7] + (double)Xi[11] * Xi[11]);
+            if (ang < c->cfg.eps_rotation && tn < c->cfg.eps_translation) break;
+        }
     }
     if (iters > c->cfg.max_iters) iters = c->cfg.max_iters;
     out->status = st;

@@ -193,6 +193,7 @@ __global__ __launch_bounds__(kPassThreads) void k_pass_identity(PassArgs a, Clou
 #pragma unroll
         for (int k = 0; k < VEC; k++) {
             if (a.max_d2 > 0.0f && d2[k] > a.max_d2) continue;
+            if (a.min_ndot > -1.0f && (npx[k] * qnx[k] + npy[k] * qny[k]) + npz[k] * qnz[k] < a.min_ndot) continue;
             acc_pair(acc, px[k], py[k], pz[k], npx[k], npy[k], npz[k], qx[k], qy[k], qz[k], qnx[k], qny[k], qnz[k], d2[k], a.pivot);
         }
     }
@@ -227,6 +228,7 @@ __global__ __launch_bounds__(kPassThreads) void k_pass_indexed(PassArgs a, const
         if (!ok) continue;
         if (a.max_d2 > 0.0f && d2 > a.max_d2) continue;
         float4 q = tq[j], nq = tn[j];
+        if (a.min_ndot > -1.0f && (npx * nq.x + npy * nq.y) + npz * nq.z < a.min_ndot) continue;
         acc_pair(acc, px, py, pz, npx, npy, npz, q.x, q.y, q.z, nq.x, nq.y, nq.z, d2, a.pivot);
     }
     acc_block_reduce_store(acc, a.partials, gridDim.x);
@@ -895,6 +897,7 @@ __global__ __launch_bounds__(kPassThreads) void k_accumulate(PassArgs a, const f
         if (pos < 0) continue;
         if (a.max_d2 > 0.0f && d2 > a.max_d2) continue;
         const float4 q = tq[pos], nq = tn[pos];
+        if (a.min_ndot > -1.0f && (npx * nq.x + npy * nq.y) + npz * nq.z < a.min_ndot) continue;
         acc_pair(acc, px, py, pz, npx, npy, npz, q.x, q.y, q.z, nq.x, nq.y, nq.z, d2, a.pivot);
     }
     acc_block_reduce_store(acc, a.partials, gridDim.x);

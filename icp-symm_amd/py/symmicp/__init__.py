@@ -38,7 +38,8 @@ class Config(C.Structure):
     _fields_ = [("struct_size", C.c_int32), ("device", C.c_int32), ("mode", C.c_int32), ("corr", C.c_int32),
                 ("apply", C.c_int32), ("max_iters", C.c_int32), ("diff_threshold", C.c_float),
                 ("max_corr_dist", C.c_float), ("fixed_iters", C.c_int32), ("sort_source", C.c_int32),
-                ("verbose", C.c_int32), ("reserved", C.c_int32 * 5)]
+                ("verbose", C.c_int32), ("min_normal_dot", C.c_float), ("eps_rotation", C.c_float),
+                ("eps_translation", C.c_float), ("reserved", C.c_int32 * 2)]
 
 
 class Sums(C.Structure):

@@ -73,7 +73,11 @@ typedef struct {
     int32_t fixed_iters;       /* != 0: ignore the threshold, run exactly max_iters iterations */
     int32_t sort_source;       /* != 0 (default for BRUTE/TREE): Morton-sort the source shard for locality */
     int32_t verbose;           /* != 0: print the reference's stdout lines (myicp.cpp:125-126,146-149) */
-    int32_t reserved[5];
+    /* robustness options of the paper-style loop; all off by default = reference behaviour */
+    float min_normal_dot;      /* > -1: drop pairs whose (transformed) source normal . target normal is below this */
+    float eps_rotation;        /* > 0 (radians) together with eps_translation > 0: also stop once an increment */
+    float eps_translation;     /*   rotates by less than eps_rotation and translates by less than eps_translation */
+    int32_t reserved[2];
 } symmicp_config;
 
 /* One reduction record = everything the host needs from one pass over the

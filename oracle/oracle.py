@@ -24,7 +24,8 @@ OK, ERR_ARG, ERR_SIZE, ERR_DEGENERATE, ERR_IO = 0, 1, 2, 3, 4
 class Config(C.Structure):
     _fields_ = [("mode", C.c_int32), ("corr", C.c_int32), ("solve", C.c_int32), ("apply", C.c_int32),
                 ("max_iters", C.c_int32), ("diff_threshold", C.c_float), ("max_corr_dist", C.c_float),
-                ("fixed_iters", C.c_int32)]
+                ("fixed_iters", C.c_int32), ("min_normal_dot", C.c_float), ("eps_rotation", C.c_float),
+                ("eps_translation", C.c_float)]
 
 
 class Result(C.Structure):
@@ -113,7 +114,7 @@ def apply(X, pts, with_translation=True):
     return out
 
 
-def reduce40(p, np_, q, nq, idx=None, pivot=None, max_d2=0.0):
+def reduce40(p, np_, q, nq, idx=None, pivot=None, max_d2=0.0, min_ndot=-2.0):
     L = lib()
     p, pp = _xyz(p); np_, npp = _xyz(np_); q, qp = _xyz(q); nq, nqp = _xyz(nq)
     S = np.zeros(NSUM, np.float64)
@@ -125,7 +126,7 @@ def reduce40(p, np_, q, nq, idx=None, pivot=None, max_d2=0.0):
     if pivot is not None:
         pivot, pv = _f(pivot)
     L.orc_reduce40(pp, npp, C.c_size_t(p.shape[0]), qp, nqp, C.c_size_t(q.shape[0]), ip, pv,
-                   C.c_float(max_d2), S.ctypes.data_as(C.POINTER(C.c_double)))
+                   C.c_float(max_d2), C.c_float(min_ndot), S.ctypes.data_as(C.POINTER(C.c_double)))
     return S
 
 
@@ -214,7 +215,8 @@ def normals_knn(xyz, k=10, viewpoint=(0.0, 0.0, 0.0)):
 
 
 def align(src_xyz, src_nrm, tgt_xyz, tgt_nrm, mode=MODE_QUIRKS, corr=CORR_IDENTITY, solve=SOLVE_GRAM,
-          apply_mode=None, max_iters=10, diff_threshold=1.0, max_corr_dist=0.0, fixed_iters=False, guess=None):
+          apply_mode=None, max_iters=10, diff_threshold=1.0, max_corr_dist=0.0, fixed_iters=False, guess=None,
+          min_normal_dot=-2.0, eps_rotation=0.0, eps_translation=0.0):
     """myicp.cpp:100-150.  Returns dict(status, transform[4,4], iters, diffs, diff_initial, diff_final, sums, rcond)."""
     L = lib()
     cfg = Config()
@@ -224,6 +226,7 @@ def align(src_xyz, src_nrm, tgt_xyz, tgt_nrm, mode=MODE_QUIRKS, corr=CORR_IDENTI
         apply_mode = APPLY_INCREMENTAL if mode == MODE_QUIRKS else APPLY_CUMULATIVE
     cfg.apply = apply_mode
     cfg.max_iters, cfg.diff_threshold, cfg.max_corr_dist, cfg.fixed_iters = max_iters, diff_threshold, max_corr_dist, int(fixed_iters)
+    cfg.min_normal_dot, cfg.eps_rotation, cfg.eps_translation = min_normal_dot, eps_rotation, eps_translation
     s, sp = _xyz(src_xyz); sn, snp = _xyz(src_nrm); t, tp = _xyz(tgt_xyz); tn, tnp = _xyz(tgt_nrm)
     gp = None
     if guess is not None:

@@ -162,7 +162,7 @@ void orc_apply(const float X[16], const float *src, float *dst, size_t n, int wi
 /* ------------------------------------------------------------------ */
 void orc_reduce40(const float *p, const float *np, size_t n_s,
                   const float *q, const float *nq, size_t n_t,
-                  const int32_t *idx, const float pivot[3], float max_d2, double S[ORC_NSUM])
+                  const int32_t *idx, const float pivot[3], float max_d2, float min_ndot, double S[ORC_NSUM])
 {
     (void)n_t;
     for (int k = 0; k < ORC_NSUM; k++) S[k] = 0.0;
@@ -174,6 +174,10 @@ void orc_reduce40(const float *p, const float *np, size_t n_s,
         const float *pi = p + 3 * i, *qj = q + 3 * j;
         float d2 = dist2f(pi, qj);
         if (max_d2 > 0.f && d2 > max_d2) continue;
+        if (min_ndot > -1.0f) {
+            const float *a = np + 3 * i, *b = nq + 3 * j;
+            if ((a[0] * b[0] + a[1] * b[1]) + a[2] * b[2] < min_ndot) continue;
+        }
         float pc[3] = {pi[0] - pv[0], pi[1] - pv[1], pi[2] - pv[2]};
         float qc[3] = {qj[0] - pv[0], qj[1] - pv[1], qj[2] - pv[2]};
         float m[3], nn[3], c;
@@ -724,6 +728,8 @@ typedef struct {
     float diff_threshold;    /* myicp.cpp:6  -> 1.0 */
     float max_corr_dist;     /* <=0: none */
     int32_t fixed_iters;     /* !=0: ignore the threshold, run exactly max_iters */
+    float min_normal_dot;    /* > -1: drop pairs with n_p . n_q below it */
+    float eps_rotation, eps_translation;   /* both > 0: also stop on a small increment */
 } orc_config;
 
 typedef struct {
@@ -740,7 +746,7 @@ void orc_config_default(orc_config *c)
 {
     memset(c, 0, sizeof(*c));
     c->mode = ORC_MODE_QUIRKS; c->corr = ORC_CORR_IDENTITY; c->solve = ORC_SOLVE_GRAM;
-    c->apply = ORC_APPLY_INCREMENTAL; c->max_iters = 10; c->diff_threshold = 1.0f;
+    c->apply = ORC_APPLY_INCREMENTAL; c->max_iters = 10; c->diff_threshold = 1.0f; c->min_normal_dot = -2.0f;
 }
 
 static void rot_only(const float X[16], float R[16])
@@ -783,7 +789,7 @@ int orc_align(const orc_config *cfg, const float *src_xyz, const float *src_nrm,
     do {                                                                                    \
         if (cfg->corr == ORC_CORR_BRUTE) orc_nn_brute(NULL, p, n_s, tgt_xyz, n_t, idx, NULL); \
         else if (cfg->corr == ORC_CORR_GRID) orc_nn_grid(grid, NULL, p, n_s, tgt_xyz, idx, NULL); \
-        orc_reduce40(p, np, n_s, tgt_xyz, tgt_nrm, n_t, idx, pivot, maxd2, S);              \
+        orc_reduce40(p, np, n_s, tgt_xyz, tgt_nrm, n_t, idx, pivot, maxd2, cfg->min_normal_dot, S); \
     } while (0)
 
     ORC_CORRESPOND_AND_REDUCE();
@@ -821,6 +827,12 @@ int orc_align(const orc_config *cfg, const float *src_xyz, const float *src_nrm,
         }
         ORC_CORRESPOND_AND_REDUCE();
         diff = (float)S[33];                                     /* :141 */
+        if (cfg->eps_rotation > 0.f && cfg->eps_translation > 0.f && !cfg->fixed_iters) {
+            double tr = ((double)Xi[0] + Xi[5] + Xi[10] - 1.0) * 0.5;
+            double ang = acos(tr > 1.0 ? 1.0 : (tr < -1.0 ? -1.0 : tr));
+            double tn = sqrt((double)Xi[3] * Xi[3] + (double)Xi[7] * Xi[7] + (double)Xi[11] * Xi[11]);
+            if (ang < cfg->eps_rotation && tn < cfg->eps_translation) break;
+        }
     }
     if (iters > cfg->max_iters) iters = cfg->max_iters;          /* iters++ overshoots by one on exit */
     memcpy(res->transform, X, sizeof(X));

@@ -498,3 +498,30 @@ def test_identity_pairs_and_distances_on_request(sym, oracle, cat, apply_mode):
     ref = ((p.astype(np.float64) - cat["tgt"]) ** 2).sum(1)
     np.testing.assert_allclose(d2, ref, rtol=2e-4)
     assert abs(np.sqrt(d2.astype(np.float64)).sum() - r["diff_final"]) < 1e-3 * r["diff_final"]
+
+
+def test_normal_compatibility_and_increment_stop(sym, oracle, cat):
+    """pairs whose normals disagree are dropped, and the loop may also stop on a small increment."""
+    # flip a third of the source normals: those pairs must drop out of the record
+    sn = cat["src_n"].copy()
+    sn[::3] *= -1
+    with sym.Engine(mode=sym.MODE_PAPER, corr=sym.CORR_TREE, min_normal_dot=0.0) as e:
+        e.set_target(cat["tgt"], cat["tgt_n"])
+        e.set_source(cat["src"], sn)
+        it = e.begin()
+        idx, _ = e.correspondences()
+        pivot = e.pivot()
+    S = oracle.reduce40(cat["src"], sn, cat["tgt"], cat["tgt_n"], idx=idx, pivot=pivot, min_ndot=0.0)
+    assert 0 < S[34] < 3400 and it["sums"][34] == S[34]
+    _sums_close(it["sums"], S)
+    # increment-based stop: same iteration count and transform as the oracle
+    kw = dict(max_iters=30, diff_threshold=0.0)
+    with sym.Engine(mode=sym.MODE_PAPER, corr=sym.CORR_TREE, eps_rotation=1e-5, eps_translation=1e-4, **kw) as e:
+        e.set_target(cat["tgt"], cat["tgt_n"])
+        e.set_source(cat["src"], cat["src_n"])
+        r = e.align()
+    ro = oracle.align(cat["src"], cat["src_n"], cat["tgt"], cat["tgt_n"], mode=oracle.MODE_PAPER, corr=oracle.CORR_BRUTE,
+                      eps_rotation=1e-5, eps_translation=1e-4, **kw)
+    assert r["status"] == 0 and r["iters"] == ro["iters"] and 4 <= r["iters"] < 30
+    assert np.abs(r["transform"] - ro["transform"]).max() < TOL_T
+    assert np.abs(r["transform"] - _truth_cat()).max() < TOL_T

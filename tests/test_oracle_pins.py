@@ -138,3 +138,16 @@ def test_incremental_vs_cumulative_apply_drift(oracle, cat):
     b = oracle.align(cat["src"], cat["src_n"], cat["tgt"], cat["tgt_n"], mode=oracle.MODE_PAPER, corr=oracle.CORR_BRUTE,
                      max_iters=30, apply_mode=oracle.APPLY_CUMULATIVE)
     assert np.abs(a["transform"] - b["transform"]).max() < 1e-4
+
+
+def test_increment_stop_and_normal_filter_in_oracle(oracle, cat):
+    full = oracle.align(cat["src"], cat["src_n"], cat["tgt"], cat["tgt_n"], mode=oracle.MODE_PAPER, corr=oracle.CORR_BRUTE,
+                        max_iters=30, diff_threshold=0.0)
+    early = oracle.align(cat["src"], cat["src_n"], cat["tgt"], cat["tgt_n"], mode=oracle.MODE_PAPER, corr=oracle.CORR_BRUTE,
+                         max_iters=30, diff_threshold=0.0, eps_rotation=1e-5, eps_translation=1e-4)
+    assert full["iters"] == 30 and 4 <= early["iters"] < 30
+    assert np.abs(full["transform"] - early["transform"]).max() < 1e-4
+    sn = cat["src_n"].copy(); sn[::2] *= -1
+    S = oracle.reduce40(cat["src"], sn, cat["tgt"], cat["tgt_n"], min_ndot=0.0)
+    S0 = oracle.reduce40(cat["src"], sn, cat["tgt"], cat["tgt_n"])
+    assert S0[34] == 3400 and 0 < S[34] < 3400
