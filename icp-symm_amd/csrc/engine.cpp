@@ -180,7 +180,7 @@ void symmicp_config_default(symmicp_config *cfg)
 static int check_cfg(const symmicp_config *cfg)
 {
     if (!cfg || cfg->struct_size != (int32_t)sizeof(symmicp_config)) return SYMMICP_ERR_ARG;
-    if (cfg->mode != SYMMICP_MODE_QUIRKS && cfg->mode != SYMMICP_MODE_PAPER) return SYMMICP_ERR_ARG;
+    if (cfg->mode < SYMMICP_MODE_QUIRKS || cfg->mode > SYMMICP_MODE_P2P) return SYMMICP_ERR_ARG;
     if (cfg->corr < SYMMICP_CORR_IDENTITY || cfg->corr > SYMMICP_CORR_TREE) return SYMMICP_ERR_ARG;
     if (cfg->apply < SYMMICP_APPLY_DEFAULT || cfg->apply > SYMMICP_APPLY_CUMULATIVE) return SYMMICP_ERR_ARG;
     if (cfg->max_iters < 0) return SYMMICP_ERR_ARG;
@@ -638,8 +638,9 @@ static int run_pass(symmicp_ctx *c, const float Xapply[16], bool from_cur, bool 
     a.tgt_offset = c->src_off;
     for (int k = 0; k < 12; k++) a.X.m[k] = Xapply[k];
     a.X.nrm_w = (c->cfg.mode == SYMMICP_MODE_QUIRKS) ? 1.0f : 0.0f;   // myicp.cpp:137 quirk
-    const bool paper = c->cfg.mode == SYMMICP_MODE_PAPER;
+    const bool paper = c->cfg.mode != SYMMICP_MODE_QUIRKS;          // PAPER and P2P take their sums about the pivot
     for (int k = 0; k < 3; k++) a.pivot[k] = paper ? c->pivot[k] : 0.0f;
+    a.p2p = c->cfg.mode == SYMMICP_MODE_P2P ? 1 : 0;
     a.max_d2 = c->cfg.max_corr_dist > 0.f ? c->cfg.max_corr_dist * c->cfg.max_corr_dist : 0.f;
     a.min_ndot = c->cfg.min_normal_dot;
     a.writeback = writeback ? 1 : 0;
@@ -795,7 +796,8 @@ int symmicp_step(symmicp_ctx *c, symmicp_iter_result *out)
     HIP_TRY(c, hipSetDevice(c->device));
     float pbar[3], qbar[3], a[3], t[3], rc = 0.f, Xi[16];
     int st = (c->cfg.mode == SYMMICP_MODE_QUIRKS) ? solve_quirks(c->last, pbar, qbar, a, t, &rc, Xi)
-                                                   : solve_paper(c->last, c->pivot, pbar, qbar, a, t, &rc, Xi);
+             : (c->cfg.mode == SYMMICP_MODE_PAPER) ? solve_paper(c->last, c->pivot, pbar, qbar, a, t, &rc, Xi)
+                                                   : solve_p2p(c->last, c->pivot, &rc, Xi);
     if (st != SYMMICP_OK) {
         c->err = "degenerate system (rank-deficient normal equations or non-finite transform; func.cpp:70,96)";
         fill_iter(c, out, st, rc, nullptr);
@@ -863,7 +865,7 @@ int symmicp_get_transform(const symmicp_ctx *c, float out16[16])
 int symmicp_get_pivot(const symmicp_ctx *c, float out3[3])
 {
     if (!c || !out3) return SYMMICP_ERR_ARG;
-    const bool paper = c->cfg.mode == SYMMICP_MODE_PAPER;
+    const bool paper = c->cfg.mode != SYMMICP_MODE_QUIRKS;
     for (int k = 0; k < 3; k++) out3[k] = paper ? c->pivot[k] : 0.f;
     return SYMMICP_OK;
 }
@@ -934,6 +936,10 @@ int symmicp_solve(int mode, const symmicp_sums *sums, const float pivot[3], floa
     if (!sums || !pbar || !qbar || !a || !t || !out16) return SYMMICP_ERR_ARG;
     if (mode == SYMMICP_MODE_QUIRKS) return solve_quirks(*sums, pbar, qbar, a, t, rcond, out16);
     if (mode == SYMMICP_MODE_PAPER) return solve_paper(*sums, pivot, pbar, qbar, a, t, rcond, out16);
+    if (mode == SYMMICP_MODE_P2P) {
+        for (int k = 0; k < 3; k++) pbar[k] = qbar[k] = a[k] = t[k] = 0.f;
+        return solve_p2p(*sums, pivot, rcond, out16);
+    }
     return SYMMICP_ERR_ARG;
 }
 

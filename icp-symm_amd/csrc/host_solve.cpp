@@ -289,6 +289,75 @@ int solve_paper(const symmicp_sums &S, const float pivot[3], float pbar[3], floa
     return SYMMICP_OK;
 }
 
+// Closed-form rigid fit of the current pairs (reference ICP/regist.h:8-72, registrateNPoint):
+//   H = sum (p - pbar)(q - qbar)^T = sum p q^T - n pbar qbar^T ;  H = U W V^T ;
+//   R = V diag(1, 1, det(V U^T)) U^T ;  T = qbar - R pbar.
+// The record holds sum p q^T (slots 0..8) and the coordinate sums about `pivot`.  The 3x3 SVD is taken through the
+// symmetric eigen-problem of H^T H (Jacobi rotations with eigenvectors).
+int solve_p2p(const symmicp_sums &S, const float pivot[3], float *rcond, float out16[16])
+{
+    const double n = S.s[34];
+    if (!(n >= 3.0)) return SYMMICP_ERR_DEGENERATE;
+    double pb[3], qb[3], H[3][3];
+    for (int k = 0; k < 3; ++k) { pb[k] = S.s[27 + k] / n; qb[k] = S.s[30 + k] / n; }
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) H[r][c] = S.s[3 * r + c] - n * pb[r] * qb[c];
+    // A = H^T H, eigen-decomposition A = V diag(w) V^T
+    double A[3][3], V[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) A[r][c] = H[0][r] * H[0][c] + H[1][r] * H[1][c] + H[2][r] * H[2][c];
+    for (int sweep = 0; sweep < 40; ++sweep) {
+        const double off = A[0][1] * A[0][1] + A[0][2] * A[0][2] + A[1][2] * A[1][2];
+        const double diag = A[0][0] * A[0][0] + A[1][1] * A[1][1] + A[2][2] * A[2][2];
+        if (off <= 1e-32 * diag) break;
+        for (int p = 0; p < 2; ++p)
+            for (int q = p + 1; q < 3; ++q) {
+                if (A[p][q] == 0.0) continue;
+                const double tau = (A[q][q] - A[p][p]) / (2.0 * A[p][q]);
+                const double t = (tau >= 0.0 ? 1.0 : -1.0) / (std::fabs(tau) + std::sqrt(1.0 + tau * tau));
+                const double c = 1.0 / std::sqrt(1.0 + t * t), s = t * c;
+                for (int k = 0; k < 3; ++k) { const double kp = A[k][p], kq = A[k][q]; A[k][p] = c * kp - s * kq; A[k][q] = s * kp + c * kq; }
+                for (int k = 0; k < 3; ++k) { const double pk = A[p][k], qk = A[q][k]; A[p][k] = c * pk - s * qk; A[q][k] = s * pk + c * qk; }
+                for (int k = 0; k < 3; ++k) { const double kp = V[k][p], kq = V[k][q]; V[k][p] = c * kp - s * kq; V[k][q] = s * kp + c * kq; }
+            }
+    }
+    int ord[3] = {0, 1, 2};
+    for (int a = 0; a < 2; ++a)
+        for (int b = a + 1; b < 3; ++b)
+            if (A[ord[b]][ord[b]] > A[ord[a]][ord[a]]) { const int t = ord[a]; ord[a] = ord[b]; ord[b] = t; }
+    double sig[3], Vs[3][3], U[3][3];
+    for (int k = 0; k < 3; ++k) {
+        const double w = A[ord[k]][ord[k]];
+        sig[k] = std::sqrt(w > 0.0 ? w : 0.0);
+        for (int r = 0; r < 3; ++r) Vs[r][k] = V[r][ord[k]];
+    }
+    if (rcond) *rcond = sig[0] > 0.0 ? (float)(sig[1] / sig[0]) : 0.f;
+    if (!(sig[1] > 1e-12 * sig[0])) return SYMMICP_ERR_DEGENERATE;           // collinear pairs: rotation undetermined
+    for (int k = 0; k < 2; ++k)
+        for (int r = 0; r < 3; ++r) U[r][k] = (H[r][0] * Vs[0][k] + H[r][1] * Vs[1][k] + H[r][2] * Vs[2][k]) / sig[k];
+    U[0][2] = U[1][0] * U[2][1] - U[2][0] * U[1][1];
+    U[1][2] = U[2][0] * U[0][1] - U[0][0] * U[2][1];
+    U[2][2] = U[0][0] * U[1][1] - U[1][0] * U[0][1];
+    double M[3][3];
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) M[r][c] = Vs[r][0] * U[c][0] + Vs[r][1] * U[c][1] + Vs[r][2] * U[c][2];
+    const double det = M[0][0] * (M[1][1] * M[2][2] - M[1][2] * M[2][1]) - M[0][1] * (M[1][0] * M[2][2] - M[1][2] * M[2][0]) +
+                       M[0][2] * (M[1][0] * M[2][1] - M[1][1] * M[2][0]);
+    const double d = det < 0.0 ? -1.0 : 1.0;                                     // regist.h:57-61
+    double R[3][3], cs[3], cd[3];
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) R[r][c] = Vs[r][0] * U[c][0] + Vs[r][1] * U[c][1] + d * Vs[r][2] * U[c][2];
+    for (int k = 0; k < 3; ++k) { cs[k] = pb[k] + (pivot ? (double)pivot[k] : 0.0); cd[k] = qb[k] + (pivot ? (double)pivot[k] : 0.0); }
+    for (int r = 0; r < 3; ++r) {
+        for (int c = 0; c < 3; ++c) out16[4 * r + c] = (float)R[r][c];
+        out16[4 * r + 3] = (float)(cd[r] - (R[r][0] * cs[0] + R[r][1] * cs[1] + R[r][2] * cs[2]));   // regist.h:65-67
+    }
+    out16[12] = out16[13] = out16[14] = 0.f; out16[15] = 1.f;
+    for (int k = 0; k < 16; ++k)
+        if (!std::isfinite(out16[k])) return SYMMICP_ERR_DEGENERATE;
+    return SYMMICP_OK;
+}
+
 // transform = incre * transform (myicp.cpp:138), fp32, k sequential
 void mat4_mul(const float A[16], const float B[16], float C[16])
 {

@@ -58,10 +58,24 @@ __device__ __forceinline__ void acc_zero(Acc &a)
 // rows of func.cpp:51-58 for one pair, accumulated in fp64
 __device__ __forceinline__ void acc_pair(Acc &a, float px, float py, float pz, float npx, float npy, float npz,
                                          float qx, float qy, float qz, float nqx, float nqy, float nqz,
-                                         float d2, const float *pivot)
+                                         float d2, const float *pivot, int p2p)
 {
     px -= pivot[0]; py -= pivot[1]; pz -= pivot[2];
     qx -= pivot[0]; qy -= pivot[1]; qz -= pivot[2];
+    if (p2p) {
+        // point-to-point (regist.h:52): 3x3 cross-covariance sums, row-major in slots 0..8
+        const double P[3] = {(double)px, (double)py, (double)pz}, Q[3] = {(double)qx, (double)qy, (double)qz};
+#pragma unroll
+        for (int r = 0; r < 3; r++)
+#pragma unroll
+            for (int c = 0; c < 3; c++) a.v[3 * r + c] = __builtin_fma(P[r], Q[c], a.v[3 * r + c]);
+        a.v[27] += P[0]; a.v[28] += P[1]; a.v[29] += P[2];
+        a.v[30] += Q[0]; a.v[31] += Q[1]; a.v[32] += Q[2];
+        a.v[33] += (double)sqrtf(d2);
+        a.v[34] += 1.0;
+        a.v[36] += (double)d2;
+        return;
+    }
     float nx = npx + nqx, ny = npy + nqy, nz = npz + nqz;            // func.cpp:51
     float sx = px + qx, sy = py + qy, sz = pz + qz;
     float dx = px - qx, dy = py - qy, dz = pz - qz;
@@ -194,7 +208,7 @@ __global__ __launch_bounds__(kPassThreads) void k_pass_identity(PassArgs a, Clou
         for (int k = 0; k < VEC; k++) {
             if (a.max_d2 > 0.0f && d2[k] > a.max_d2) continue;
             if (a.min_ndot > -1.0f && (npx[k] * qnx[k] + npy[k] * qny[k]) + npz[k] * qnz[k] < a.min_ndot) continue;
-            acc_pair(acc, px[k], py[k], pz[k], npx[k], npy[k], npz[k], qx[k], qy[k], qz[k], qnx[k], qny[k], qnz[k], d2[k], a.pivot);
+            acc_pair(acc, px[k], py[k], pz[k], npx[k], npy[k], npz[k], qx[k], qy[k], qz[k], qnx[k], qny[k], qnz[k], d2[k], a.pivot, a.p2p);
         }
     }
     acc_block_reduce_store(acc, a.partials, gridDim.x);
@@ -229,7 +243,7 @@ __global__ __launch_bounds__(kPassThreads) void k_pass_indexed(PassArgs a, const
         if (a.max_d2 > 0.0f && d2 > a.max_d2) continue;
         float4 q = tq[j], nq = tn[j];
         if (a.min_ndot > -1.0f && (npx * nq.x + npy * nq.y) + npz * nq.z < a.min_ndot) continue;
-        acc_pair(acc, px, py, pz, npx, npy, npz, q.x, q.y, q.z, nq.x, nq.y, nq.z, d2, a.pivot);
+        acc_pair(acc, px, py, pz, npx, npy, npz, q.x, q.y, q.z, nq.x, nq.y, nq.z, d2, a.pivot, a.p2p);
     }
     acc_block_reduce_store(acc, a.partials, gridDim.x);
 }
@@ -898,7 +912,7 @@ __global__ __launch_bounds__(kPassThreads) void k_accumulate(PassArgs a, const f
         if (a.max_d2 > 0.0f && d2 > a.max_d2) continue;
         const float4 q = tq[pos], nq = tn[pos];
         if (a.min_ndot > -1.0f && (npx * nq.x + npy * nq.y) + npz * nq.z < a.min_ndot) continue;
-        acc_pair(acc, px, py, pz, npx, npy, npz, q.x, q.y, q.z, nq.x, nq.y, nq.z, d2, a.pivot);
+        acc_pair(acc, px, py, pz, npx, npy, npz, q.x, q.y, q.z, nq.x, nq.y, nq.z, d2, a.pivot, a.p2p);
     }
     acc_block_reduce_store(acc, a.partials, gridDim.x);
 }

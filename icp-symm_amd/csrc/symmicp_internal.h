@@ -90,6 +90,7 @@ struct PassArgs {
     float pivot[3];          // subtracted from p and q before forming rows (0 in QUIRKS)
     float max_d2;            // <= 0: keep all pairs
     float min_ndot;          // <= -1: keep all pairs; else drop pairs with n_p . n_q below it
+    int32_t p2p;             // point-to-point mode: slots 0..8 accumulate p q^T instead of the 6x6 Gram / rhs
     int32_t writeback;
     // correspondences
     const unsigned long long *best64;   // BRUTE: (d2 bits << 32 | target row), ~0 = none

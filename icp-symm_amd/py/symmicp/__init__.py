@@ -20,7 +20,7 @@ LIB_PATH = os.path.join(_ROOT, "lib", "libsymmicp.so")
 NSUM = 40
 UNIQUE_ID_BYTES = 128
 OK, ERR_ARG, ERR_SIZE, ERR_DEGENERATE, ERR_IO, ERR_HIP, ERR_STATE, ERR_COMM = range(8)
-MODE_QUIRKS, MODE_PAPER = 0, 1
+MODE_QUIRKS, MODE_PAPER, MODE_P2P = 0, 1, 2
 CORR_IDENTITY, CORR_BRUTE, CORR_TREE = 0, 1, 2
 APPLY_DEFAULT, APPLY_INCREMENTAL, APPLY_CUMULATIVE = 0, 1, 2
 

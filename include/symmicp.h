@@ -45,8 +45,11 @@ typedef enum {
  * the full affine applied to the normals (myicp.cpp:137).  PAPER is the
  * formulation the reference's own comments intend (func.cpp:84,94;
  * Rusinkiewicz 2019): centred rows, joint 6x6 solve, T(q)RT(t)RT(-p),
- * normals rotated only. */
-typedef enum { SYMMICP_MODE_QUIRKS = 0, SYMMICP_MODE_PAPER = 1 } symmicp_mode;
+ * normals rotated only.  P2P is the closed-form point-to-point fit of the reference's
+ * regist.h:8-72 (registrateNPoint: centroids, 3x3 cross-covariance, SVD, reflection fix) run as an
+ * ICP loop -- what the RegisterP2P stub (myicp.cpp:43-59) was heading for; record slots 0..8 then hold
+ * sum p q^T instead of the symmetric-objective Gram matrix. */
+typedef enum { SYMMICP_MODE_QUIRKS = 0, SYMMICP_MODE_PAPER = 1, SYMMICP_MODE_P2P = 2 } symmicp_mode;
 
 /* Correspondence.  IDENTITY is what the reference does (myicp.cpp:130, the
  * search is a todo at :128-131).  BRUTE and TREE are exact nearest neighbour

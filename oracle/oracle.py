@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
 
 NSUM = 40
-MODE_QUIRKS, MODE_PAPER = 0, 1
+MODE_QUIRKS, MODE_PAPER, MODE_P2P = 0, 1, 2
 CORR_IDENTITY, CORR_BRUTE, CORR_GRID = 0, 1, 2
 SOLVE_GRAM, SOLVE_LITERAL = 0, 1
 APPLY_INCREMENTAL, APPLY_CUMULATIVE = 0, 1
@@ -114,7 +114,7 @@ def apply(X, pts, with_translation=True):
     return out
 
 
-def reduce40(p, np_, q, nq, idx=None, pivot=None, max_d2=0.0, min_ndot=-2.0):
+def reduce40(p, np_, q, nq, idx=None, pivot=None, max_d2=0.0, min_ndot=-2.0, p2p=False):
     L = lib()
     p, pp = _xyz(p); np_, npp = _xyz(np_); q, qp = _xyz(q); nq, nqp = _xyz(nq)
     S = np.zeros(NSUM, np.float64)
@@ -126,7 +126,7 @@ def reduce40(p, np_, q, nq, idx=None, pivot=None, max_d2=0.0, min_ndot=-2.0):
     if pivot is not None:
         pivot, pv = _f(pivot)
     L.orc_reduce40(pp, npp, C.c_size_t(p.shape[0]), qp, nqp, C.c_size_t(q.shape[0]), ip, pv,
-                   C.c_float(max_d2), C.c_float(min_ndot), S.ctypes.data_as(C.POINTER(C.c_double)))
+                   C.c_float(max_d2), C.c_float(min_ndot), C.c_int(int(p2p)), S.ctypes.data_as(C.POINTER(C.c_double)))
     return S
 
 
@@ -174,6 +174,26 @@ def compose(pbar, qbar, a, t, paper=False):
     (L.orc_compose_paper if paper else L.orc_compose_quirks)(*ptrs, X.ctypes.data_as(C.POINTER(C.c_float)))
     del args
     return X.reshape(4, 4)
+
+
+def kabsch(src, dst):
+    """regist.h:8-72 registrateNPoint on index pairs -> (R [3,3] f64, T [3] f64, status); dst ~ R src + T"""
+    L = lib()
+    s_, sp = _xyz(src); d_, dp = _xyz(dst)
+    R = np.zeros(9, np.float64); T = np.zeros(3, np.float64)
+    st = L.orc_kabsch(sp, dp, C.c_size_t(s_.shape[0]), R.ctypes.data_as(C.POINTER(C.c_double)), T.ctypes.data_as(C.POINTER(C.c_double)))
+    return R.reshape(3, 3), T, st
+
+
+def solve_p2p(S, pivot=None):
+    L = lib()
+    S = np.ascontiguousarray(S, np.float64)
+    X = np.zeros(16, np.float32)
+    pv = None
+    if pivot is not None:
+        pivot, pv = _f(pivot)
+    st = L.orc_solve_p2p(S.ctypes.data_as(C.POINTER(C.c_double)), pv, X.ctypes.data_as(C.POINTER(C.c_float)))
+    return st, X.reshape(4, 4)
 
 
 def nn_brute(p, q, X=None):

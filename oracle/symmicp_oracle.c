@@ -15,6 +15,7 @@
  *   orc_align             myicp.cpp:100-150 RegisterSymm loop
  *   orc_normals_knn       myicp.cpp:152-172 estimateNormals (PCL k=10 PCA)
  *   orc_pcd_read          myicp.cpp:20-31  LoadCloud (ASCII/binary PCD v0.7)
+ *   orc_kabsch / orc_solve_p2p   regist.h:8-72   registrateNPoint (closed-form rigid fit)
  * plus the capability the reference leaves as a todo (myicp.cpp:128-131,
  * func.cpp:36-40): exact nearest-neighbour correspondence (orc_nn_brute,
  * orc_nn_grid) and the paper-correct solve the reference's own comments
@@ -52,7 +53,7 @@
 
 #define ORC_NSUM 40
 
-enum { ORC_MODE_QUIRKS = 0, ORC_MODE_PAPER = 1 };
+enum { ORC_MODE_QUIRKS = 0, ORC_MODE_PAPER = 1, ORC_MODE_P2P = 2 };
 enum { ORC_CORR_IDENTITY = 0, ORC_CORR_BRUTE = 1, ORC_CORR_GRID = 2 };
 enum { ORC_SOLVE_GRAM = 0, ORC_SOLVE_LITERAL = 1 };
 enum { ORC_APPLY_INCREMENTAL = 0, ORC_APPLY_CUMULATIVE = 1 };
@@ -162,7 +163,7 @@ void orc_apply(const float X[16], const float *src, float *dst, size_t n, int wi
 /* ------------------------------------------------------------------ */
 void orc_reduce40(const float *p, const float *np, size_t n_s,
                   const float *q, const float *nq, size_t n_t,
-                  const int32_t *idx, const float pivot[3], float max_d2, float min_ndot, double S[ORC_NSUM])
+                  const int32_t *idx, const float pivot[3], float max_d2, float min_ndot, int p2p, double S[ORC_NSUM])
 {
     (void)n_t;
     for (int k = 0; k < ORC_NSUM; k++) S[k] = 0.0;
@@ -182,16 +183,22 @@ void orc_reduce40(const float *p, const float *np, size_t n_s,
         float qc[3] = {qj[0] - pv[0], qj[1] - pv[1], qj[2] - pv[2]};
         float m[3], nn[3], c;
         row_f32(pc, np + 3 * i, qc, nq + 3 * j, m, nn, &c);
-        double v[6] = {m[0], m[1], m[2], nn[0], nn[1], nn[2]};
-        int k = 0;
-        for (int a = 0; a < 6; a++)
-            for (int b = a; b < 6; b++)
-                S[k++] += v[a] * v[b];
-        for (int a = 0; a < 6; a++) S[21 + a] += v[a] * (double)c;
+        if (p2p) {
+            /* point-to-point (regist.h:52): slots 0..8 = sum p q^T about the pivot, row-major */
+            for (int a = 0; a < 3; a++)
+                for (int b = 0; b < 3; b++) S[3 * a + b] += (double)pc[a] * (double)qc[b];
+        } else {
+            double v[6] = {m[0], m[1], m[2], nn[0], nn[1], nn[2]};
+            int k = 0;
+            for (int a = 0; a < 6; a++)
+                for (int b = a; b < 6; b++)
+                    S[k++] += v[a] * v[b];
+            for (int a = 0; a < 6; a++) S[21 + a] += v[a] * (double)c;
+        }
         for (int a = 0; a < 3; a++) { S[27 + a] += (double)pc[a]; S[30 + a] += (double)qc[a]; }
         S[33] += (double)sqrtf(d2);
         S[34] += 1.0;
-        S[35] += (double)c * (double)c;
+        if (!p2p) S[35] += (double)c * (double)c;
         S[36] += (double)d2;
     }
 }
@@ -717,6 +724,96 @@ int orc_normals_knn(const float *xyz, size_t n, int k, const float vp[3], float 
 }
 
 /* ------------------------------------------------------------------ */
+/* regist.h:8-72 registrateNPoint: closed-form rigid fit of known pairs  */
+/* (Kabsch).  S = sum (src-c_s)(dst-c_d)^T ; S = U W V^T ;                */
+/* R = V diag(1,1,det(V U^T)) U^T ; T = c_d - R c_s   (dst ~ R src + T).  */
+/* The 3x3 SVD is done through the eigen-decomposition of S^T S.          */
+/* ------------------------------------------------------------------ */
+static double det3(const double M[9])
+{
+    return M[0] * (M[4] * M[8] - M[5] * M[7]) - M[1] * (M[3] * M[8] - M[5] * M[6]) + M[2] * (M[3] * M[7] - M[4] * M[6]);
+}
+
+int orc_kabsch_from_cov(const double S[9], const double cs[3], const double cd[3], double R[9], double T[3])
+{
+    double StS[9], V[9], w[3];
+    for (int r = 0; r < 3; r++)
+        for (int c = 0; c < 3; c++) {
+            double x = 0;
+            for (int k = 0; k < 3; k++) x += S[k * 3 + r] * S[k * 3 + c];
+            StS[r * 3 + c] = x;
+        }
+    jacobi_eig(3, StS, V, w);
+    /* sort eigenpairs descending */
+    int ord[3] = {0, 1, 2};
+    for (int a = 0; a < 2; a++)
+        for (int b = a + 1; b < 3; b++)
+            if (w[ord[b]] > w[ord[a]]) { int t = ord[a]; ord[a] = ord[b]; ord[b] = t; }
+    double Vs[9], sig[3], U[9];
+    for (int k = 0; k < 3; k++) {
+        sig[k] = sqrt(w[ord[k]] > 0 ? w[ord[k]] : 0);
+        for (int r = 0; r < 3; r++) Vs[r * 3 + k] = V[r * 3 + ord[k]];
+    }
+    if (!(sig[1] > 1e-12 * sig[0])) return ORC_ERR_DEGENERATE;      /* rank < 2: rotation undetermined */
+    for (int k = 0; k < 2; k++)
+        for (int r = 0; r < 3; r++) {
+            double x = 0;
+            for (int c = 0; c < 3; c++) x += S[r * 3 + c] * Vs[c * 3 + k];
+            U[r * 3 + k] = x / sig[k];
+        }
+    /* third left vector: u2 = u0 x u1 (also covers sig[2] ~ 0) */
+    U[0 * 3 + 2] = U[1 * 3 + 0] * U[2 * 3 + 1] - U[2 * 3 + 0] * U[1 * 3 + 1];
+    U[1 * 3 + 2] = U[2 * 3 + 0] * U[0 * 3 + 1] - U[0 * 3 + 0] * U[2 * 3 + 1];
+    U[2 * 3 + 2] = U[0 * 3 + 0] * U[1 * 3 + 1] - U[1 * 3 + 0] * U[0 * 3 + 1];
+    /* make V right-handed the same way so that S = U diag(sig) V^T stays a valid factorisation up to the sign of the
+       last pair, which the determinant fix below absorbs */
+    double VUt[9];
+    for (int r = 0; r < 3; r++)
+        for (int c = 0; c < 3; c++) {
+            double x = 0;
+            for (int k = 0; k < 3; k++) x += Vs[r * 3 + k] * U[c * 3 + k];
+            VUt[r * 3 + c] = x;
+        }
+    double d = det3(VUt) < 0 ? -1.0 : 1.0;                          /* regist.h:57-61 */
+    for (int r = 0; r < 3; r++)
+        for (int c = 0; c < 3; c++)
+            R[r * 3 + c] = Vs[r * 3 + 0] * U[c * 3 + 0] + Vs[r * 3 + 1] * U[c * 3 + 1] + d * Vs[r * 3 + 2] * U[c * 3 + 2];
+    for (int r = 0; r < 3; r++) T[r] = cd[r] - (R[r * 3 + 0] * cs[0] + R[r * 3 + 1] * cs[1] + R[r * 3 + 2] * cs[2]);   /* :65-67 */
+    return ORC_OK;
+}
+
+/* literal entry point: pairs by index, doubles throughout (regist.h works on cv::Point3d) */
+int orc_kabsch(const float *src, const float *dst, size_t n, double R[9], double T[3])
+{
+    if (n < 3) return ORC_ERR_SIZE;
+    double cs[3] = {0, 0, 0}, cd[3] = {0, 0, 0}, S[9] = {0};
+    for (size_t i = 0; i < n; i++)
+        for (int k = 0; k < 3; k++) { cs[k] += src[3 * i + k]; cd[k] += dst[3 * i + k]; }
+    for (int k = 0; k < 3; k++) { cs[k] /= (double)n; cd[k] /= (double)n; }
+    for (size_t i = 0; i < n; i++)
+        for (int r = 0; r < 3; r++)
+            for (int c = 0; c < 3; c++) S[r * 3 + c] += (src[3 * i + r] - cs[r]) * (dst[3 * i + c] - cd[c]);
+    return orc_kabsch_from_cov(S, cs, cd, R, T);
+}
+
+/* the same from one reduction record taken in point-to-point mode (sums about `pivot`) */
+int orc_solve_p2p(const double S40[ORC_NSUM], const float pivot[3], float X[16])
+{
+    double n = S40[34];
+    if (!(n >= 3)) return ORC_ERR_DEGENERATE;
+    double pb[3], qb[3], H[9], cs[3], cd[3], R[9], T[3];
+    for (int k = 0; k < 3; k++) { pb[k] = S40[27 + k] / n; qb[k] = S40[30 + k] / n; }
+    for (int r = 0; r < 3; r++)
+        for (int c = 0; c < 3; c++) H[r * 3 + c] = S40[3 * r + c] - n * pb[r] * qb[c];
+    for (int k = 0; k < 3; k++) { cs[k] = pb[k] + (pivot ? pivot[k] : 0.0); cd[k] = qb[k] + (pivot ? pivot[k] : 0.0); }
+    int st = orc_kabsch_from_cov(H, cs, cd, R, T);
+    if (st != ORC_OK) return st;
+    mat4_identity(X);
+    for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) X[r * 4 + c] = (float)R[r * 3 + c]; X[r * 4 + 3] = (float)T[r]; }
+    return ORC_OK;
+}
+
+/* ------------------------------------------------------------------ */
 /* myicp.cpp:100-150 RegisterSymm loop                                   */
 /* ------------------------------------------------------------------ */
 typedef struct {
@@ -766,7 +863,8 @@ int orc_align(const orc_config *cfg, const float *src_xyz, const float *src_nrm,
     orc_grid *grid = (cfg->corr == ORC_CORR_GRID) ? orc_grid_build(tgt_xyz, n_t, 2.0f) : NULL;
     float X[16]; mat4_identity(X);
     if (guess) memcpy(X, guess, sizeof(X));
-    int paper = cfg->mode == ORC_MODE_PAPER;
+    int paper = cfg->mode != ORC_MODE_QUIRKS;      /* PAPER and P2P: centred sums, normals rotate only */
+    int p2p = cfg->mode == ORC_MODE_P2P;
     /* working copies (myicp.cpp:109-111); a guess is applied up front */
     if (guess) {
         orc_apply(X, src_xyz, p, n_s, 1);
@@ -789,7 +887,7 @@ int orc_align(const orc_config *cfg, const float *src_xyz, const float *src_nrm,
     do {                                                                                    \
         if (cfg->corr == ORC_CORR_BRUTE) orc_nn_brute(NULL, p, n_s, tgt_xyz, n_t, idx, NULL); \
         else if (cfg->corr == ORC_CORR_GRID) orc_nn_grid(grid, NULL, p, n_s, tgt_xyz, idx, NULL); \
-        orc_reduce40(p, np, n_s, tgt_xyz, tgt_nrm, n_t, idx, pivot, maxd2, cfg->min_normal_dot, S); \
+        orc_reduce40(p, np, n_s, tgt_xyz, tgt_nrm, n_t, idx, pivot, maxd2, cfg->min_normal_dot, cfg->mode == ORC_MODE_P2P, S); \
     } while (0)
 
     ORC_CORRESPOND_AND_REDUCE();
@@ -800,7 +898,9 @@ int orc_align(const orc_config *cfg, const float *src_xyz, const float *src_nrm,
         float pbar[3], qbar[3], a[3], t[3], Xi[16];
         double rc = 1.0;
         int st;
-        if (!paper) {
+        if (p2p) {
+            st = orc_solve_p2p(S, pivot, Xi);
+        } else if (!paper) {
             if (cfg->solve == ORC_SOLVE_LITERAL && cfg->corr == ORC_CORR_IDENTITY)
                 st = orc_solve_quirks_literal(p, np, tgt_xyz, tgt_nrm, n_s, pbar, qbar, a, t);
             else

@@ -126,3 +126,14 @@ def test_reference_main_cpp_compiles_unchanged_against_the_dropin(sym, tmp_path)
         shutil.copy(os.path.join(GOLDEN, "cat_out.pcd"), tmp_path / "cat_out.pcd")
         r = subprocess.run([str(exe)], cwd=tmp_path, capture_output=True, text=True, timeout=120)
         assert "no usable gfx950 HIP device" in r.stderr and "Result transform" not in r.stdout
+
+
+def test_host_solve_p2p_matches_oracle(sym, oracle, cat):
+    pivot = cat["tgt"].astype(np.float64).mean(0).astype(np.float32)
+    S = oracle.reduce40(cat["src"], cat["src_n"], cat["tgt"], cat["tgt_n"], pivot=pivot, p2p=True)
+    st, _, _, _, _, rc, X = sym.solve(sym.MODE_P2P, S, pivot)
+    st2, X2 = oracle.solve_p2p(S, pivot)
+    assert st == st2 == 0 and np.abs(X - X2).max() < 1e-6
+    c, s = np.cos(np.pi / 4), np.sin(np.pi / 4)
+    T = np.array([[c, -s, 0, 2.5], [s, c, 0, 0], [0, 0, 1, 0], [0, 0, 0, 1]])
+    assert np.abs(X - T).max() < 1e-5

@@ -525,3 +525,22 @@ def test_normal_compatibility_and_increment_stop(sym, oracle, cat):
     assert r["status"] == 0 and r["iters"] == ro["iters"] and 4 <= r["iters"] < 30
     assert np.abs(r["transform"] - ro["transform"]).max() < TOL_T
     assert np.abs(r["transform"] - _truth_cat()).max() < TOL_T
+
+
+@pytest.mark.parametrize("corr", ["identity", "tree"])
+def test_align_point_to_point_mode(sym, oracle, cat, corr):
+    """closed-form point-to-point fit (reference regist.h:8-72) as an ICP loop on the GPU reduction"""
+    with sym.Engine(mode=sym.MODE_P2P, corr=getattr(sym, "CORR_" + corr.upper()), max_iters=60) as e:
+        e.set_target(cat["tgt"], cat["tgt_n"])
+        e.set_source(cat["src"], cat["src_n"])
+        it = e.begin()
+        pivot = e.pivot()
+        idx, _ = e.correspondences()
+        r = e.align()
+    S = oracle.reduce40(cat["src"], cat["src_n"], cat["tgt"], cat["tgt_n"], idx=idx, pivot=pivot, p2p=True)
+    _sums_close(it["sums"], S)
+    ro = oracle.align(cat["src"], cat["src_n"], cat["tgt"], cat["tgt_n"], mode=oracle.MODE_P2P,
+                      corr=oracle.CORR_IDENTITY if corr == "identity" else oracle.CORR_BRUTE, max_iters=60)
+    assert r["status"] == 0 and r["iters"] == ro["iters"]
+    assert np.abs(r["transform"] - ro["transform"]).max() < TOL_T
+    assert np.abs(r["transform"] - _truth_cat()).max() < TOL_T

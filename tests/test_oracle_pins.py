@@ -151,3 +151,33 @@ def test_increment_stop_and_normal_filter_in_oracle(oracle, cat):
     S = oracle.reduce40(cat["src"], sn, cat["tgt"], cat["tgt_n"], min_ndot=0.0)
     S0 = oracle.reduce40(cat["src"], sn, cat["tgt"], cat["tgt_n"])
     assert S0[34] == 3400 and 0 < S[34] < 3400
+
+
+def test_pin_kabsch_on_the_reference_pair(oracle, cat):
+    """regist.h:8-72 (registrateNPoint) on the index-paired cat clouds -- what ICP/register-test.cpp:55-66 prints --
+    must return the generating motion Rz(45 deg), (2.5, 0, 0)."""
+    R, T, st = oracle.kabsch(cat["src"], cat["tgt"])
+    c, s = np.cos(np.pi / 4), np.sin(np.pi / 4)
+    assert st == 0
+    assert np.abs(R - [[c, -s, 0], [s, c, 0], [0, 0, 1]]).max() < 1e-6
+    assert np.abs(T - [2.5, 0, 0]).max() < 1e-5
+    assert abs(np.linalg.det(R) - 1) < 1e-9
+    # numpy cross-check of the SVD route
+    ps = cat["src"].astype(np.float64); pd = cat["tgt"].astype(np.float64)
+    H = (ps - ps.mean(0)).T @ (pd - pd.mean(0))
+    U, W, Vt = np.linalg.svd(H)
+    Rn = Vt.T @ np.diag([1, 1, np.linalg.det(Vt.T @ U.T)]) @ U.T
+    assert np.abs(R - Rn).max() < 1e-9
+    # reflection case: mirrored target still yields a proper rotation
+    R2, _, st2 = oracle.kabsch(cat["src"], cat["tgt"] * np.float32([1, 1, -1]))
+    assert st2 == 0 and abs(np.linalg.det(R2) - 1) < 1e-9
+
+
+def test_p2p_icp_in_oracle(oracle, cat):
+    r = oracle.align(cat["src"], cat["src_n"], cat["tgt"], cat["tgt_n"], mode=oracle.MODE_P2P, corr=oracle.CORR_IDENTITY)
+    assert r["status"] == 0 and r["iters"] == 1
+    c, s = np.cos(np.pi / 4), np.sin(np.pi / 4)
+    T = np.array([[c, -s, 0, 2.5], [s, c, 0, 0], [0, 0, 1, 0], [0, 0, 0, 1]])
+    assert np.abs(r["transform"] - T).max() < 1e-5
+    r = oracle.align(cat["src"], cat["src_n"], cat["tgt"], cat["tgt_n"], mode=oracle.MODE_P2P, corr=oracle.CORR_BRUTE, max_iters=60)
+    assert r["status"] == 0 and np.abs(r["transform"] - T).max() < 1e-4
