@@ -82,6 +82,9 @@ def main():
         uid = [symmicp.comm_get_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(uid, src=0)
         eng.comm_init_rank(world, rank, uid[0])
+    elif os.environ.get("SYMMICP_FORCE_COMM"):
+        # rehearsal of the multi-GPU data path on one GPU: a real 1-rank RCCL communicator (all-reduce + publish per pass)
+        eng.comm_init_rank(1, 0, symmicp.comm_get_unique_id())
     t0 = time.perf_counter()
     eng.set_target(d["tgt"], d["tgt_n"])
     eng.set_source(d["src"], d["src_n"])

@@ -133,6 +133,22 @@ int MyICP::align(float out4x4[16], const float *guess4x4)
 	return st;
 }
 
+pcl::PointCloud<PointT>::Ptr MyICP::GetAlignedSrcCloud() const
+{
+	pcl::PointCloud<PointT>::Ptr out(new pcl::PointCloud<PointT>);
+	const float *X = transform_;
+	out->points.resize(cloud_src->points.size());
+	for (size_t i = 0; i < cloud_src->points.size(); i++) {
+		const PointT &p = cloud_src->points[i];
+		PointT &q = out->points[i];
+		q.x = ((X[0] * p.x + X[1] * p.y) + X[2] * p.z) + X[3];
+		q.y = ((X[4] * p.x + X[5] * p.y) + X[6] * p.z) + X[7];
+		q.z = ((X[8] * p.x + X[9] * p.y) + X[10] * p.z) + X[11];
+	}
+	out->width = (uint32_t)out->points.size(); out->height = 1;
+	return out;
+}
+
 void MyICP::RegisterSymm()
 {
 	// myicp.cpp:100-150; the loop itself (and its stdout lines) runs inside symmicp_align

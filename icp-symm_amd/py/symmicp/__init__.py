@@ -440,3 +440,8 @@ class MyICP:
 
     def getFinalTransformation(self):
         return self._final
+
+    def GetAlignedSrcCloud(self):
+        """the source moved by the final transform (the reference never writes its result back, myicp.cpp:109-111)"""
+        X = self._final.astype(np.float64)
+        return (self.cloud_src.astype(np.float64) @ X[:3, :3].T + X[:3, 3]).astype(np.float32)

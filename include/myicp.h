@@ -38,6 +38,8 @@ public:
 	void setInputTarget(const float *xyz, const float *normals, size_t n);
 	int align(float out4x4[16] = nullptr, const float *guess4x4 = nullptr);   // returns symmicp_status
 	const float *getFinalTransformation() const { return transform_; }       // row-major 4x4
+	// the source cloud moved by the final transform (the reference never writes its result back: myicp.cpp:109-111,146-149)
+	pcl::PointCloud<PointT>::Ptr GetAlignedSrcCloud() const;
 	void setMaximumIterations(int n) { max_iters = n; }
 	void setDiffThreshold(float d) { diff_threshold = d; }
 	void setMode(symmicp_mode m) { mode_ = m; }                    // default SYMMICP_MODE_QUIRKS (= the reference)
