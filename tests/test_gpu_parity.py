@@ -544,3 +544,49 @@ def test_align_point_to_point_mode(sym, oracle, cat, corr):
     assert r["status"] == 0 and r["iters"] == ro["iters"]
     assert np.abs(r["transform"] - ro["transform"]).max() < TOL_T
     assert np.abs(r["transform"] - _truth_cat()).max() < TOL_T
+
+
+def test_partial_overlap_different_sizes_and_max_distance(sym, oracle):
+    """N_s != N_t, clouds that only partly overlap, pairs beyond max_corr_dist dropped: record and result vs the oracle"""
+    from symmicp import synth
+    d = synth.c4_surface(40000)
+    src = d["src"][d["src"][:, 0] < 0.7][:23000]
+    sn = d["src_n"][d["src"][:, 0] < 0.7][:23000]
+    keep = d["tgt"][:, 0] > 0.25
+    tgt, tn = d["tgt"][keep], d["tgt_n"][keep]
+    assert len(src) != len(tgt)
+    kw = dict(max_iters=12, fixed_iters=1, max_corr_dist=0.02)
+    with sym.Engine(mode=sym.MODE_PAPER, corr=sym.CORR_TREE, **kw) as e:
+        e.set_target(tgt, tn)
+        e.set_source(src, sn)
+        it = e.begin()
+        idx, d2 = e.correspondences()
+        S = oracle.reduce40(src, sn, tgt, tn, idx=idx, pivot=e.pivot(), max_d2=0.02 ** 2)
+        assert 0 < S[34] < len(src) and it["sums"][34] == S[34]
+        _sums_close(it["sums"], S)
+        ri, rd = oracle.nn_grid(src, tgt)
+        assert np.array_equal(idx, ri) and np.array_equal(d2, rd)
+        r = e.align()
+    ro = oracle.align(src, sn, tgt, tn, mode=oracle.MODE_PAPER, corr=oracle.CORR_GRID, max_iters=12, fixed_iters=True, max_corr_dist=0.02)
+    assert r["status"] == ro["status"] == 0 and r["iters"] == ro["iters"] == 12
+    assert np.abs(r["transform"] - ro["transform"]).max() < TOL_T
+    assert np.abs(r["transform"] - d["truth"]).max() < 5e-4
+
+
+def test_second_alignment_on_the_same_context(sym, oracle, cat):
+    """re-using a ctx (new clouds, new config) must not leak state: certificates, work lists, counters"""
+    from symmicp import synth
+    d = synth.c4_surface(20000)
+    with sym.Engine(mode=sym.MODE_PAPER, corr=sym.CORR_TREE, max_iters=8, fixed_iters=1) as e:
+        e.set_target(d["tgt"], d["tgt_n"])
+        e.set_source(d["src"], d["src_n"])
+        r1 = e.align()
+        r1b = e.align()                                   # same clouds again: bit-identical
+        assert np.array_equal(r1["transform"], r1b["transform"])
+        e.set_target(cat["tgt"], cat["tgt_n"])            # different clouds on the same ctx
+        e.set_source(cat["src"], cat["src_n"])
+        e.set_config(max_iters=30, fixed_iters=0)
+        r2 = e.align()
+    assert np.abs(r1["transform"] - d["truth"]).max() < 1e-4
+    ro = oracle.align(cat["src"], cat["src_n"], cat["tgt"], cat["tgt_n"], mode=oracle.MODE_PAPER, corr=oracle.CORR_BRUTE, max_iters=30)
+    assert r2["iters"] == ro["iters"] and np.abs(r2["transform"] - ro["transform"]).max() < TOL_T
