@@ -373,7 +373,8 @@ static int build_octree(symmicp_ctx *c, const uint32_t *keys, const float4 *tq, 
     ix->olevel_off[NL] = (uint32_t)total;
     if (total > 0xFFFFFFull * NL) { hipFree(nid); return fail(c, SYMMICP_ERR_SIZE, "octree too large"); }
     for (int l = 0; l < NL; l++)
-        if (cnt[l] > 0xFFFFFFu) { hipFree(nid); return fail(c, SYMMICP_ERR_SIZE, "octree level exceeds 2^24 nodes"); }
+        // child_first is a 24-bit field (node word and walk stack word): targets beyond ~16.7M distinct finest cells are refused
+        if (cnt[l] > 0xFFFFFFu) { hipFree(nid); return fail(c, SYMMICP_ERR_SIZE, "octree level exceeds 2^24 nodes (target cloud too large for SYMMICP_CORR_TREE)"); }
     uint32_t *first = nullptr;
     float4 *nodes = nullptr;
     HIP_TRY(c, hipMalloc((void **)&first, sizeof(uint32_t) * (total + 1)));
