@@ -134,7 +134,7 @@ def main():
     err_truth = float(np.abs(T - d["truth"]).max())
 
     # ---- roofline of the dominant kernel, measured live with HIP events on the ctx stream -------------
-    # One pass = k_search_cells -> k_search_walk_wave -> k_search_walk -> k_accumulate (-> k_final_reduce).
+    # One pass = k_search_cells -> k_search_walk -> k_accumulate (-> k_final_reduce).
     # The dominant kernel is the one with the largest total time over the timed region; its average launch
     # duration prices the pass's algorithmic bytes (N_loc*(48+4+4) + N_t*12 per launch).
     names = symmicp.KERNEL_SLOTS
@@ -146,8 +146,8 @@ def main():
     # pass duration from the two events per pass recorded INSIDE the timed region (all kernels of one pass, without the final reduce)
     pass_ms = st_timed["sum_pass_ms"] / max(1, st_timed["passes"])
     split = "k_search_cells" in kern
-    # The NN pass is four kernels; the contract's algorithmic bytes are per PASS, so they are priced against the
-    # summed average duration of the pass's kernels (pricing them against one of the four would flatter it).
+    # The NN pass is three kernels; the contract's algorithmic bytes are per PASS, so they are priced against the
+    # summed average duration of the pass's kernels (pricing them against one of the three would flatter it).
     unit_name = "+".join(k for k in names[:4] if k in kern and k != "(gap)") if split else dom
     achieved = alg_bytes / (pass_ms * 1e-3) / 1e9 if pass_ms > 0 else 0.0
     # HBM traffic per pass: PMC counters cannot be read from inside this process, so they come from the committed

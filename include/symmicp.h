@@ -190,7 +190,7 @@ typedef struct {
     int64_t pass_blocks;
     int64_t bytes_algorithmic_per_pass;  /* N_s*(48+4+4)+N_t*12 (NN) or N_s*48 (identity) [+24 N_s write-back] */
     /* per-kernel HIP-event time since the last reset (timing mode), slots:
-     * 0 k_search_cells, 1 k_search_walk_wave, 2 k_search_walk, 3 k_accumulate, 4 k_final_reduce,
+     * 0 k_search_cells, 1 idle gap between cells and walk, 2 k_search_walk, 3 k_accumulate, 4 k_final_reduce,
      * 5 the single pass kernel of the IDENTITY / BRUTE modes (k_pass_identity, or k_nn_brute + k_pass_indexed),
      * 6 the whole pass bracketed by two events (timing mode 1) */
     double kernel_ms[8];
