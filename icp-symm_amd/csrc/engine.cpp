@@ -102,7 +102,8 @@ struct symmicp_ctx {
     // reduction
     int pass_blocks = 0;
     double *partials = nullptr, *d_sums = nullptr, *h_sums = nullptr, *h_sums_dev = nullptr;   // h_sums: 40 doubles + sequence word
-    uint32_t *ticket = nullptr;
+    uint32_t *ticket = nullptr;          // [0] ticket of the final reduce, [1] length of the last pass's work list
+    long long last_list_len = -1;        // host copy of [1]; -1 = unknown (full walk grid)
     unsigned long long seq = 0;
     // loop state
     bool begun = false;
@@ -211,7 +212,7 @@ int symmicp_create(const symmicp_config *cfg, symmicp_ctx **out)
     bool ok = hipMalloc((void **)&c->partials, sizeof(double) * kNSum * 8192) == hipSuccess &&
               hipMalloc((void **)&c->d_sums, sizeof(double) * kNSum) == hipSuccess &&
               hipHostMalloc((void **)&c->h_sums, sizeof(double) * (kNSum + 8), hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess &&
-              hipMalloc((void **)&c->ticket, sizeof(uint32_t)) == hipSuccess && hipMemset(c->ticket, 0, sizeof(uint32_t)) == hipSuccess &&
+              hipMalloc((void **)&c->ticket, 2 * sizeof(uint32_t)) == hipSuccess && hipMemset(c->ticket, 0, 2 * sizeof(uint32_t)) == hipSuccess &&
               hipHostGetDevicePointer((void **)&c->h_sums_dev, c->h_sums, 0) == hipSuccess &&
               std::memset(c->h_sums, 0, sizeof(double) * (kNSum + 8)) != nullptr &&
               true;
@@ -693,13 +694,23 @@ static int run_pass(symmicp_ctx *c, const float Xapply[16], bool from_cur, bool 
         break;
     default:
         {
-            // the accumulate kernel is streaming: 8 blocks per CU worth of grid, a multiple of 8 for the XCD remap
-            static const int acc_cap = std::getenv("SYMMICP_ACC_BLOCKS") ? std::atoi(std::getenv("SYMMICP_ACC_BLOCKS")) : 2048;
+            // the accumulate kernel is streaming with a 40-value block reduction at the end of every block: 2 blocks per
+            // CU measured best (18 us at 512 blocks, 23 us at 2048, 1M points); a multiple of 8 for the XCD remap
+            static const int acc_cap = std::getenv("SYMMICP_ACC_BLOCKS") ? std::atoi(std::getenv("SYMMICP_ACC_BLOCKS")) : 512;
             const int nb_all = (int)((c->n_loc + kPassThreads - 1) / kPassThreads);
             int ab = nb_all < acc_cap ? ((nb_all + 7) / 8) * 8 : acc_cap;
             c->pass_blocks = blocks = ab;
+            // Walk grid: any size is correct (the kernel strides over the list); sized from the previous pass's list
+            // length, which only shrinks while an alignment converges.  Unknown or long lists get the full grid.
+            uint32_t wb = 0;
+            if (!first && c->last_list_len >= 0 && c->last_list_len <= 50000) {
+                wb = (uint32_t)(2 * c->last_list_len);
+                if (wb < 256u) wb = 256u;
+                if (wb > 8192u) wb = 8192u;
+            }
+            if (std::getenv("SYMMICP_WALK_FULL_GRID")) wb = 0;
             // per-kernel events only in timing mode 2; mode 1 brackets the pass (events 0 and 4)
-            launch_pass_tree_split(a, c->ix, c->wl, ab, c->stream, c->timing == 2 ? ev : nullptr);
+            launch_pass_tree_split(a, c->ix, c->wl, ab, wb, c->stream, c->timing == 2 ? ev : nullptr);
             if (ev && c->timing == 2) c->ev_split[c->ev_used] = 2;
         }
         break;
@@ -707,11 +718,11 @@ static int run_pass(symmicp_ctx *c, const float Xapply[16], bool from_cur, bool 
     if (ev && c->ev_split[c->ev_used] != 2) hipEventRecord(ev[4], c->stream);
     const unsigned long long seq = ++c->seq;
     volatile unsigned long long *flag = reinterpret_cast<volatile unsigned long long *>(c->h_sums + kNSum);
-    launch_final_reduce(c->partials, blocks, c->d_sums, c->comm ? nullptr : c->h_sums_dev, c->ticket, seq, c->wl_count, c->stream);
+    launch_final_reduce(c->partials, blocks, c->d_sums, c->comm ? nullptr : c->h_sums_dev, c->ticket, seq, c->wl_count, c->ticket + 1, c->stream);
     if (c->comm) {
         int r = g_rccl.AllReduce(c->d_sums, c->d_sums, kNSum, kNcclFloat64, kNcclSum, c->comm, c->stream);
         if (r != 0) return fail(c, SYMMICP_ERR_COMM, std::string("ncclAllReduce: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?"));
-        launch_publish(c->d_sums, c->h_sums_dev, seq, c->stream);
+        launch_publish(c->d_sums, c->ticket + 1, c->h_sums_dev, seq, c->stream);
     }
     if (ev) {
         // the final-reduce time is only separated out in per-kernel mode; otherwise event 5 is event 4 again
@@ -744,9 +755,11 @@ static int run_pass(symmicp_ctx *c, const float Xapply[16], bool from_cur, bool 
         unsigned long long h[8];
         hipMemcpy(h, c->ix.dbg, sizeof(h), hipMemcpyDeviceToHost);
         hipMemset(c->ix.dbg, 0, sizeof(h));
-        std::fprintf(stderr, "[symmicp dbg] pass %lld: walk steps=%llu visits=%llu wave-max-steps*64=%llu\n", (long long)c->st.passes, h[3], h[4], h[5]);
+        std::fprintf(stderr, "[symmicp dbg] pass %lld: cells: certified=%llu scans=%llu probes=%llu to-walk=%llu items=%llu points=%llu | walk visits=%llu wave-max*64=%llu\n",
+                     (long long)c->st.passes, h[1], h[2], h[6], h[7], h[0], h[3], h[4], h[5]);
     }
     std::memcpy(c->last.s, c->h_sums, sizeof(double) * kNSum);
+    c->last_list_len = (c->cfg.corr == SYMMICP_CORR_TREE) ? (long long)reinterpret_cast<volatile unsigned long long *>(c->h_sums)[kNSum + 1] : -1;
     c->st.passes++;
     return SYMMICP_OK;
 }

@@ -476,11 +476,12 @@ __device__ __forceinline__ float axis_gap2(float p, float origin, int c, float h
 //
 // Pair certificates.  The search ball is padded by D = kSlackFrac * h beyond the previous pair's distance, so after
 // the scan every target point other than the winner is known to be at least L = min(second-nearest scanned, bound + D)
-// away from the query position p_ref.  If the query later sits at p with |p - p_ref| = delta, any other point is
-// >= L - delta away and the old winner <= d1 + delta, so while 2*delta < L - d1 (=: slack) the nearest neighbour is
-// provably the same point and the scan is skipped; only its distance is refreshed.  Once ICP has converged almost
-// every pair is certified and the kernel is little more than phase 1.  Margins of 1e-5 relative cover fp32 rounding
-// (distance evaluations are good to ~4e-7); exact ties give slack 0 and are always searched again.
+// away from the query position p_ref (the "clear radius", stored in PassArgs::slack; 0 = no certificate).  If the
+// query later sits at p with |p - p_ref| = delta, any other point is >= L - delta away from it, so while the winner's
+// current distance d1' satisfies d1' + delta < L the nearest neighbour is provably the same point and the scan is
+// skipped; only the distance is refreshed.  Once ICP has converged almost every pair is certified and the kernel is
+// little more than phase 1.  Margins of 1e-5 relative cover fp32 rounding (distance evaluations are good to ~4e-7);
+// exact ties give L <= d1, i.e. no certificate, and are always searched again.
 // ---------------------------------------------------------------------------
 constexpr float kSlackFrac = 0.25f;
 
@@ -514,9 +515,9 @@ __global__ __launch_bounds__(kPassThreads) void k_search_cells(PassArgs a, Targe
         if (prev >= 0 && (uint32_t)prev < ix.n) test_point(b, ix.tq[prev], prev, px, py, pz);
         bool certified = false;
         if (a.use_slack && b.pos >= 0) {
-            const float sl = a.slack[i];
+            const float clear = a.slack[i];                                               // L (0: no certificate)
             const float m2 = dist2(px, py, pz, a.ref_x[i], a.ref_y[i], a.ref_z[i]);      // delta^2
-            certified = (4.0f * m2) * 1.00002f < sl * sl;
+            certified = (__builtin_amdgcn_sqrtf(b.d2) + __builtin_amdgcn_sqrtf(m2)) * 1.00002f < clear;      // 1-ulp roots, inside the margin
         }
         if (certified) {
             a.d2_out[i] = b.d2;          // same pair, refreshed distance; position, certificate unchanged
@@ -648,6 +649,7 @@ __global__ __launch_bounds__(kPassThreads) void k_search_cells(PassArgs a, Targe
             const uint32_t cx = (c0 & 1023u) + (uint32_t)kx, cy = ((c0 >> 10) & 1023u) + (uint32_t)ky, cz = (c0 >> 20) + (uint32_t)kz;
             const uint2 rng = cell_range(ix, (spread3(cz) << 2) | (spread3(cy) << 1) | spread3(cx));
             const float qx = s_px[q], qy = s_py[q], qz = s_pz[q];
+            if (ix.dbg) atomicAdd(ix.dbg + 3, (unsigned long long)(rng.y - rng.x));
             for (uint32_t j = rng.x; j < rng.y; j += 4) {
                 float4 t4[4];
 #pragma unroll
@@ -682,6 +684,16 @@ __global__ __launch_bounds__(kPassThreads) void k_search_cells(PassArgs a, Targe
     }
     __syncthreads();
 
+    if (ix.dbg) {
+        // debug counters: [0] (query,cell) items, [1] certified, [2] cell scans, [6] probes, [7] handed to the walk in phase 1
+        if (tid == 0) atomicAdd(ix.dbg + 0, (unsigned long long)total);
+        const unsigned long long mc = __ballot(active && !defer && !searched && !probe), ms = __ballot(searched), mp = __ballot(probe), md = __ballot(defer);
+        if (lane == 0) {
+            atomicAdd(ix.dbg + 1, (unsigned long long)__popcll(mc)); atomicAdd(ix.dbg + 2, (unsigned long long)__popcll(ms));
+            atomicAdd(ix.dbg + 6, (unsigned long long)__popcll(mp)); atomicAdd(ix.dbg + 7, (unsigned long long)__popcll(md));
+        }
+    }
+
     // ---- phase 3 ----
     if (active && (searched || probe)) {
         const unsigned long long key = s_key[tid];
@@ -698,7 +710,7 @@ __global__ __launch_bounds__(kPassThreads) void k_search_cells(PassArgs a, Targe
             const float second = sqrtf(__uint_as_float(s_second[tid])) * 0.99999f;
             const float L = fminf(second, lim * 0.99999f);
             a.ref_x[i] = px; a.ref_y[i] = py; a.ref_z[i] = pz;
-            a.slack[i] = fmaxf(L - d1, 0.0f);
+            a.slack[i] = (L > d1) ? L : 0.0f;
         }
     }
 }
@@ -755,22 +767,24 @@ __global__ __launch_bounds__(kWalkThreads, 6) void k_search_walk(PassArgs a, Tar
     sl_prefix(wl.work, pre);
     const float inf = __int_as_float(0x7f800000);
     if (pre[kShards] > kWaveModeMax) {
-        // ---- long list: one thread per entry ----
-        uint32_t i;
-        if (!sl_locate(wl.work, pre, blockIdx.x * kWalkThreads + threadIdx.x, i)) return;
-        const float x = a.in.x[i], y = a.in.y[i], z = a.in.z[i];
-        const float px = xf_row(a.X.m + 0, x, y, z, 1.0f), py = xf_row(a.X.m + 4, x, y, z, 1.0f), pz = xf_row(a.X.m + 8, x, y, z, 1.0f);
-        Best b;
-        b.pos = a.pos_out[i]; b.d2 = a.d2_out[i]; b.row = 0x7fffffff;
-        if (b.pos >= 0) b.row = __float_as_int(ix.tq[b.pos].w);
-        const uint32_t visits = oct_walk(ix, px, py, pz, b);
-        a.pos_out[i] = b.pos;
-        a.d2_out[i] = b.d2;
-        if (ix.dbg) {
-            uint32_t mx = visits;
-            for (int off = 32; off > 0; off >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, off, 64));
-            atomicAdd(ix.dbg + 4, (unsigned long long)visits);
-            if ((threadIdx.x & 63) == 0) atomicAdd(ix.dbg + 5, (unsigned long long)mx * 64ull);
+        // ---- long list: one thread per entry (the launcher normally sizes the grid so that this loop runs once) ----
+        for (uint32_t g = blockIdx.x * kWalkThreads + threadIdx.x; ; g += gridDim.x * kWalkThreads) {
+            uint32_t i;
+            if (!sl_locate(wl.work, pre, g, i)) break;
+            const float x = a.in.x[i], y = a.in.y[i], z = a.in.z[i];
+            const float px = xf_row(a.X.m + 0, x, y, z, 1.0f), py = xf_row(a.X.m + 4, x, y, z, 1.0f), pz = xf_row(a.X.m + 8, x, y, z, 1.0f);
+            Best b;
+            b.pos = a.pos_out[i]; b.d2 = a.d2_out[i]; b.row = 0x7fffffff;
+            if (b.pos >= 0) b.row = __float_as_int(ix.tq[b.pos].w);
+            const uint32_t visits = oct_walk(ix, px, py, pz, b);
+            a.pos_out[i] = b.pos;
+            a.d2_out[i] = b.d2;
+            if (ix.dbg) {
+                uint32_t mx = visits;
+                for (int off = 32; off > 0; off >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, off, 64));
+                atomicAdd(ix.dbg + 4, (unsigned long long)visits);
+                if ((threadIdx.x & 63) == 0) atomicAdd(ix.dbg + 5, (unsigned long long)mx * 64ull);
+            }
         }
         return;
     }
@@ -879,7 +893,7 @@ __global__ __launch_bounds__(kWalkThreads, 6) void k_search_walk(PassArgs a, Tar
             const float d1 = sqrtf(__uint_as_float((uint32_t)(bkey >> 32)));
             const float L = fminf(sqrtf(__uint_as_float(second)), d1 + pad) * 0.99999f;
             a.ref_x[i] = px; a.ref_y[i] = py; a.ref_z[i] = pz;
-            a.slack[i] = fmaxf(L - d1 * 1.00001f, 0.0f);
+            a.slack[i] = (L > d1 * 1.00001f) ? L : 0.0f;
         }
         if (lane == 0) {
             a.pos_out[i] = bpos;
@@ -888,6 +902,9 @@ __global__ __launch_bounds__(kWalkThreads, 6) void k_search_walk(PassArgs a, Tar
     }
 }
 
+// The pair's distance is recomputed from the gathered q (bit-identical to the stored one) instead of being read.
+// (A 4-points-per-thread variant with 16-byte column loads was measured and is no faster: the two 16-byte gathers per
+// pair bound this kernel, not the column loads.  Few blocks are: each one ends in a 40-value block reduction.)
 __global__ __launch_bounds__(kPassThreads) void k_accumulate(PassArgs a, const float4 *__restrict__ tq, const float4 *__restrict__ tn)
 {
     Acc acc; acc_zero(acc);
@@ -900,7 +917,6 @@ __global__ __launch_bounds__(kPassThreads) void k_accumulate(PassArgs a, const f
         const float x = a.in.x[i], y = a.in.y[i], z = a.in.z[i];
         const float nx = a.in.nx[i], ny = a.in.ny[i], nz = a.in.nz[i];
         const int32_t pos = a.pos_out[i];
-        const float d2 = a.d2_out[i];
         const float px = xf_row(a.X.m + 0, x, y, z, 1.0f), py = xf_row(a.X.m + 4, x, y, z, 1.0f), pz = xf_row(a.X.m + 8, x, y, z, 1.0f);
         const float npx = xf_row(a.X.m + 0, nx, ny, nz, a.X.nrm_w), npy = xf_row(a.X.m + 4, nx, ny, nz, a.X.nrm_w),
                     npz = xf_row(a.X.m + 8, nx, ny, nz, a.X.nrm_w);
@@ -909,8 +925,9 @@ __global__ __launch_bounds__(kPassThreads) void k_accumulate(PassArgs a, const f
             a.out.nx[i] = npx; a.out.ny[i] = npy; a.out.nz[i] = npz;
         }
         if (pos < 0) continue;
-        if (a.max_d2 > 0.0f && d2 > a.max_d2) continue;
         const float4 q = tq[pos], nq = tn[pos];
+        const float d2 = dist2(px, py, pz, q.x, q.y, q.z);
+        if (a.max_d2 > 0.0f && d2 > a.max_d2) continue;
         if (a.min_ndot > -1.0f && (npx * nq.x + npy * nq.y) + npz * nq.z < a.min_ndot) continue;
         acc_pair(acc, px, py, pz, npx, npy, npz, q.x, q.y, q.z, nq.x, nq.y, nq.z, d2, a.pivot, a.p2p);
     }
@@ -924,7 +941,7 @@ __global__ __launch_bounds__(kPassThreads) void k_accumulate(PassArgs a, const f
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_final_reduce(const double *__restrict__ partials, int nblocks,
                                                       double *out_dev, double *out_host, uint32_t *ticket,
-                                                      unsigned long long seq, uint32_t *counters_to_clear)
+                                                      unsigned long long seq, uint32_t *counters_to_clear, uint32_t *list_len_dev)
 {
     __shared__ double red[256];
     const int k = blockIdx.x, t = threadIdx.x;
@@ -948,9 +965,19 @@ __global__ __launch_bounds__(256) void k_final_reduce(const double *__restrict__
     }
     __syncthreads();
     if (last) {
-        // shard counters of the pass's append lists: zero again for the next pass
-        if (counters_to_clear)
+        // shard counters of the pass's append lists: report the work list's length (it sizes the next pass's walk
+        // grid), then zero them for the next pass
+        if (counters_to_clear) {
+            if (t < 64) {
+                uint32_t v = counters_to_clear[t * kShardStride];
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) v += (uint32_t)__shfl_xor((int)v, off, 64);
+                if (t == 0 && out_host) reinterpret_cast<volatile unsigned long long *>(out_host)[kNSum + 1] = v;
+                if (t == 0) *list_len_dev = v;
+            }
+            __syncthreads();
             for (int c = t; c < 3 * kShards; c += 256) counters_to_clear[c * kShardStride] = 0;
+        }
         if (t == 0) {
             *ticket = 0;
             if (out_host) {
@@ -962,9 +989,11 @@ __global__ __launch_bounds__(256) void k_final_reduce(const double *__restrict__
 }
 
 // multi-GPU: after the RCCL all-reduce, copy the record to host-mapped memory and publish the sequence number
-__global__ __launch_bounds__(64) void k_publish(const double *__restrict__ sums_dev, double *out_host, unsigned long long seq)
+__global__ __launch_bounds__(64) void k_publish(const double *__restrict__ sums_dev, const uint32_t *__restrict__ list_len_dev,
+                                                double *out_host, unsigned long long seq)
 {
     if (threadIdx.x < kNSum) out_host[threadIdx.x] = sums_dev[threadIdx.x];
+    if (threadIdx.x == 0) reinterpret_cast<volatile unsigned long long *>(out_host)[kNSum + 1] = *list_len_dev;
     __threadfence_system();
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -1069,7 +1098,13 @@ uint32_t shard_capacity(uint32_t n_points)
     return ((nbp + kShards - 1) / kShards) * kPassThreads;
 }
 
-void launch_pass_tree_split(const PassArgs &a, const TargetIndex &ix, const WorkLists &wl, int acc_blocks, hipStream_t s, hipEvent_t *ev)
+uint32_t walk_blocks_full(const WorkLists &wl)
+{
+    return kShards * (wl.work.cap / kWalkThreads);      // one thread per possible list entry
+}
+
+void launch_pass_tree_split(const PassArgs &a, const TargetIndex &ix, const WorkLists &wl, int acc_blocks, uint32_t walk_blocks,
+                            hipStream_t s, hipEvent_t *ev)
 {
     static const uint32_t wave_mode_max = getenv("SYMMICP_WAVE_MODE_MAX") ? (uint32_t)atol(getenv("SYMMICP_WAVE_MODE_MAX")) : 200000u;   // work lists longer than this use one thread per query
     // all shard counters are zero here: cleared by the previous pass's final reduce
@@ -1079,23 +1114,23 @@ void launch_pass_tree_split(const PassArgs &a, const TargetIndex &ix, const Work
     hipLaunchKernelGGL(k_search_cells, dim3(nbp), dim3(kPassThreads), 0, s, a, ix, wl);
     if (ev) hipEventRecord(ev[1], s);
     if (ev) hipEventRecord(ev[2], s);
-    const uint32_t list_blocks = kShards * (wl.work.cap / kWalkThreads);      // enough blocks for one thread per list entry
-    hipLaunchKernelGGL(k_search_walk, dim3(list_blocks), dim3(kWalkThreads), 0, s, a, ix, wl, wave_mode_max);
+    if (walk_blocks == 0 || walk_blocks > walk_blocks_full(wl)) walk_blocks = walk_blocks_full(wl);
+    hipLaunchKernelGGL(k_search_walk, dim3(walk_blocks), dim3(kWalkThreads), 0, s, a, ix, wl, wave_mode_max);
     if (ev) hipEventRecord(ev[3], s);
     hipLaunchKernelGGL(k_accumulate, dim3(acc_blocks), dim3(kPassThreads), 0, s, a, ix.tq, ix.tn);
     if (ev) hipEventRecord(ev[4], s);
 }
 
 void launch_final_reduce(const double *partials, int blocks, double *out_dev, double *out_host_mapped, uint32_t *ticket,
-                         unsigned long long seq, uint32_t *counters_to_clear, hipStream_t s)
+                         unsigned long long seq, uint32_t *counters_to_clear, uint32_t *list_len_dev, hipStream_t s)
 {
     hipLaunchKernelGGL(k_final_reduce, dim3(kNSum), dim3(256), 0, s, partials, blocks, out_dev, out_host_mapped, ticket, seq,
-                       counters_to_clear);
+                       counters_to_clear, list_len_dev);
 }
 
-void launch_publish(const double *sums_dev, double *out_host_mapped, unsigned long long seq, hipStream_t s)
+void launch_publish(const double *sums_dev, const uint32_t *list_len_dev, double *out_host_mapped, unsigned long long seq, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, s, sums_dev, out_host_mapped, seq);
+    hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, s, sums_dev, list_len_dev, out_host_mapped, seq);
 }
 
 void launch_nn_brute(const CloudSoA &src, uint32_t n_s, const Affine &X, const float4 *tq, uint32_t n_t,
