@@ -494,6 +494,7 @@ __global__ __launch_bounds__(kPassThreads) void k_search_cells(PassArgs a, Targe
     __shared__ uint32_t s_cell0[kPassThreads];
     __shared__ uint16_t s_items[kPassThreads * 27];
     __shared__ uint32_t s_wsum[kPassThreads / 64 + 1];
+    __shared__ uint32_t s_anyw[kPassThreads / 64];     // per-wave flags for block-wide "any" votes
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t shard = blockIdx.x & (kShards - 1);
@@ -505,18 +506,27 @@ __global__ __launch_bounds__(kPassThreads) void k_search_cells(PassArgs a, Targe
     float px = 0.f, py = 0.f, pz = 0.f;
     Best b;
     b.d2 = inf; b.pos = -1; b.row = 0x7fffffff;
-    uint32_t mask = 0;                 // surviving cells of this query, bit = kx + 3*ky + 9*kz
+    uint32_t mask = 0;                 // cells of this query to scan this round, bit = kx + 3*ky + 9*kz
+    uint32_t mask_rest = 0;            // probe: the other cells of the 3x3x3 block, scanned only if the 2x2x2 block cannot prove its best
     bool defer = false, searched = false, probe = false;
-    float lim = 0.f;                   // everything outside the scanned cells is at least this far from the query
+    float lim = 0.f, lim_full = 0.f;   // everything outside the scanned cells is at least this far from the query
     if (active) {
+        // Two memory round trips decide a certified pair: everything addressed by i first (the certificate is loaded
+        // whether or not it will be needed), then the previous winner as one 16-byte load.
         const float x = a.in.x[i], y = a.in.y[i], z = a.in.z[i];
         const int32_t prev = a.pos_prev ? a.pos_prev[i] : -1;
+        float clear = 0.0f, rx = 0.0f, ry = 0.0f, rz = 0.0f;                              // L (0: no certificate), p_ref
+        if (a.use_slack) { clear = a.slack[i]; rx = a.ref_x[i]; ry = a.ref_y[i]; rz = a.ref_z[i]; }
         px = xf_row(a.X.m + 0, x, y, z, 1.0f); py = xf_row(a.X.m + 4, x, y, z, 1.0f); pz = xf_row(a.X.m + 8, x, y, z, 1.0f);
-        if (prev >= 0 && (uint32_t)prev < ix.n) test_point(b, ix.tq[prev], prev, px, py, pz);
+        if (prev >= 0 && (uint32_t)prev < ix.n) {
+            const float4 q = ix.tq[prev];
+            const float d2 = dist2(px, py, pz, q.x, q.y, q.z);
+            const int32_t row = __float_as_int(q.w);
+            if (d2 <= inf) { b.d2 = d2; b.pos = prev; b.row = row; }                      // (not NaN)
+        }
         bool certified = false;
         if (a.use_slack && b.pos >= 0) {
-            const float clear = a.slack[i];                                               // L (0: no certificate)
-            const float m2 = dist2(px, py, pz, a.ref_x[i], a.ref_y[i], a.ref_z[i]);      // delta^2
+            const float m2 = dist2(px, py, pz, rx, ry, rz);                               // delta^2
             certified = (__builtin_amdgcn_sqrtf(b.d2) + __builtin_amdgcn_sqrtf(m2)) * 1.00002f < clear;      // 1-ulp roots, inside the margin
         }
         if (certified) {
@@ -571,24 +581,41 @@ __global__ __launch_bounds__(kPassThreads) void k_search_cells(PassArgs a, Targe
                     const int cx = (int)fx, cy = (int)fy, cz = (int)fz;
                     const int x0 = max(cx - 1, 0), y0 = max(cy - 1, 0), z0 = max(cz - 1, 0);
                     const int x1 = min(cx + 1, ix.gdim - 1), y1 = min(cy + 1, ix.gdim - 1), z1 = min(cz + 1, ix.gdim - 1);
-                    const int nx = x1 - x0, ny = y1 - y0, nz = z1 - z0;
+                    // first round: the 2x2x2 cells nearest to the query (the query's cell and, per axis, the neighbour on
+                    // the side of the nearer face); bits are relative to (x0, y0, z0) like those of the full block
+                    const int ax = max(cx - ((fx - (float)cx) < 0.5f ? 1 : 0), 0), bx = min(ax + 1, ix.gdim - 1);
+                    const int ay = max(cy - ((fy - (float)cy) < 0.5f ? 1 : 0), 0), by = min(ay + 1, ix.gdim - 1);
+                    const int az = max(cz - ((fz - (float)cz) < 0.5f ? 1 : 0), 0), bz = min(az + 1, ix.gdim - 1);
 #pragma unroll
                     for (int kz = 0; kz < 3; kz++)
 #pragma unroll
                         for (int ky = 0; ky < 3; ky++)
 #pragma unroll
-                            for (int kx = 0; kx < 3; kx++)
-                                if (kx <= nx && ky <= ny && kz <= nz) mask |= 1u << (kx + 3 * ky + 9 * kz);
+                            for (int kx = 0; kx < 3; kx++) {
+                                const int X = x0 + kx, Y = y0 + ky, Z = z0 + kz;
+                                const uint32_t bit = 1u << (kx + 3 * ky + 9 * kz);
+                                if (X <= x1 && Y <= y1 && Z <= z1) {
+                                    if (X >= ax && X <= bx && Y >= ay && Y <= by && Z >= az && Z <= bz) mask |= bit;
+                                    else mask_rest |= bit;
+                                }
+                            }
                     s_cell0[tid] = (uint32_t)x0 | ((uint32_t)y0 << 10) | ((uint32_t)z0 << 20);
-                    // distance from the query to the nearest face of the block that has cells beyond it
-                    float face = inf;
+                    // distance from the query to the nearest face, with cells beyond it, of the small and of the full block
+                    float face = inf, face8 = inf;
                     if (x0 > 0) face = fminf(face, px - (ix.ox + (float)x0 * ix.h));
                     if (y0 > 0) face = fminf(face, py - (ix.oy + (float)y0 * ix.h));
                     if (z0 > 0) face = fminf(face, pz - (ix.oz + (float)z0 * ix.h));
                     if (x1 < ix.gdim - 1) face = fminf(face, (ix.ox + (float)(x1 + 1) * ix.h) - px);
                     if (y1 < ix.gdim - 1) face = fminf(face, (ix.oy + (float)(y1 + 1) * ix.h) - py);
                     if (z1 < ix.gdim - 1) face = fminf(face, (ix.oz + (float)(z1 + 1) * ix.h) - pz);
-                    lim = face - 2e-3f * ix.h;      // everything outside the block is at least this far away
+                    if (ax > 0) face8 = fminf(face8, px - (ix.ox + (float)ax * ix.h));
+                    if (ay > 0) face8 = fminf(face8, py - (ix.oy + (float)ay * ix.h));
+                    if (az > 0) face8 = fminf(face8, pz - (ix.oz + (float)az * ix.h));
+                    if (bx < ix.gdim - 1) face8 = fminf(face8, (ix.ox + (float)(bx + 1) * ix.h) - px);
+                    if (by < ix.gdim - 1) face8 = fminf(face8, (ix.oy + (float)(by + 1) * ix.h) - py);
+                    if (bz < ix.gdim - 1) face8 = fminf(face8, (ix.oz + (float)(bz + 1) * ix.h) - pz);
+                    lim = face8 - 2e-3f * ix.h;          // everything outside the scanned block is at least this far away
+                    lim_full = face - 2e-3f * ix.h;
                     probe = true;
                     defer = false;
                 }
@@ -605,6 +632,8 @@ __global__ __launch_bounds__(kPassThreads) void k_search_cells(PassArgs a, Targe
     s_pos[tid] = b.pos;
     s_key[tid] = (b.pos >= 0) ? (((unsigned long long)__float_as_uint(b.d2) << 32) | (unsigned long long)(uint32_t)b.row) : ~0ull;
     s_second[tid] = 0x7f800000u;
+    uint32_t total = 0, total_all = 0;
+    for (int round = 0; round < 2; round++) {
     // block-wide exclusive prefix sum of the item counts
     const uint32_t cnt = (uint32_t)__popc(mask);
     uint32_t incl = cnt;
@@ -614,13 +643,26 @@ __global__ __launch_bounds__(kPassThreads) void k_search_cells(PassArgs a, Targe
         if (lane >= off) incl += u;
     }
     if (lane == 63) s_wsum[wave] = incl;
+    if (round == 0) {
+        const unsigned long long any3 = __ballot(searched || probe);
+        if (lane == 0) s_anyw[wave] = (any3 != 0ull);
+    }
     __syncthreads();
-    uint32_t base = 0, total = 0;
+    uint32_t base = 0;
+    total = 0;
 #pragma unroll
     for (int w = 0; w < kPassThreads / 64; w++) {
         const uint32_t ws = s_wsum[w];
         if (w < wave) base += ws;
         total += ws;
+    }
+    total_all += total;
+    if (round == 0 && !ix.dbg) {
+        // the common block of a converged pass: every pair certified (or handed to the walk), nothing to scan or store
+        uint32_t any = 0;
+#pragma unroll
+        for (int w = 0; w < kPassThreads / 64; w++) any |= s_anyw[w];
+        if (!any) return;
     }
     {
         uint32_t slot = base + incl - cnt;
@@ -632,7 +674,6 @@ __global__ __launch_bounds__(kPassThreads) void k_search_cells(PassArgs a, Targe
         }
     }
     __syncthreads();
-
     // ---- phase 2 ----
     for (uint32_t it0 = 0; it0 < total; it0 += kPassThreads) {
         const uint32_t it = it0 + tid;
@@ -684,9 +725,28 @@ __global__ __launch_bounds__(kPassThreads) void k_search_cells(PassArgs a, Targe
     }
     __syncthreads();
 
+    // A probe that scanned its 2x2x2 block: done if the best point is closer than the nearest outer face of that block,
+    // else the other cells of the 3x3x3 block are scanned in a second round (about one query in ten on a surface cloud).
+    bool more = false;
+    if (round == 0 && probe) {
+        const float d1 = sqrtf(__uint_as_float((uint32_t)(s_key[tid] >> 32))) * 1.00001f;
+        if (!(d1 < lim)) { more = (mask_rest != 0); lim = lim_full; }
+    }
+    mask = more ? mask_rest : 0u;
+    if (round == 1) break;
+    {
+        const unsigned long long anym = __ballot(more);
+        if (lane == 0) s_anyw[wave] = (anym != 0ull);
+        __syncthreads();
+        uint32_t any = 0;
+#pragma unroll
+        for (int w = 0; w < kPassThreads / 64; w++) any |= s_anyw[w];
+        if (!any) break;
+    }
+    }
     if (ix.dbg) {
         // debug counters: [0] (query,cell) items, [1] certified, [2] cell scans, [6] probes, [7] handed to the walk in phase 1
-        if (tid == 0) atomicAdd(ix.dbg + 0, (unsigned long long)total);
+        if (tid == 0) atomicAdd(ix.dbg + 0, (unsigned long long)total_all);
         const unsigned long long mc = __ballot(active && !defer && !searched && !probe), ms = __ballot(searched), mp = __ballot(probe), md = __ballot(defer);
         if (lane == 0) {
             atomicAdd(ix.dbg + 1, (unsigned long long)__popcll(mc)); atomicAdd(ix.dbg + 2, (unsigned long long)__popcll(ms));
