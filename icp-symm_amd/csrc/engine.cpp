@@ -102,8 +102,8 @@ struct symmicp_ctx {
     // reduction
     int pass_blocks = 0;
     double *partials = nullptr, *d_sums = nullptr, *h_sums = nullptr, *h_sums_dev = nullptr;   // h_sums: 40 doubles + sequence word
-    uint32_t *ticket = nullptr;          // [0] ticket of the final reduce, [1] length of the last pass's work list
-    long long last_list_len = -1;        // host copy of [1]; -1 = unknown (full walk grid)
+    uint32_t *ticket = nullptr;          // ticket of the final reduce
+    long long last_list_len = -1;        // work-list length of the last pass (all ranks); -1 = unknown (full walk grid)
     unsigned long long seq = 0;
     // loop state
     bool begun = false;
@@ -212,7 +212,7 @@ int symmicp_create(const symmicp_config *cfg, symmicp_ctx **out)
     bool ok = hipMalloc((void **)&c->partials, sizeof(double) * kNSum * 8192) == hipSuccess &&
               hipMalloc((void **)&c->d_sums, sizeof(double) * kNSum) == hipSuccess &&
               hipHostMalloc((void **)&c->h_sums, sizeof(double) * (kNSum + 8), hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess &&
-              hipMalloc((void **)&c->ticket, 2 * sizeof(uint32_t)) == hipSuccess && hipMemset(c->ticket, 0, 2 * sizeof(uint32_t)) == hipSuccess &&
+              hipMalloc((void **)&c->ticket, sizeof(uint32_t)) == hipSuccess && hipMemset(c->ticket, 0, sizeof(uint32_t)) == hipSuccess &&
               hipHostGetDevicePointer((void **)&c->h_sums_dev, c->h_sums, 0) == hipSuccess &&
               std::memset(c->h_sums, 0, sizeof(double) * (kNSum + 8)) != nullptr &&
               true;
@@ -668,6 +668,8 @@ static int run_pass(symmicp_ctx *c, const float Xapply[16], bool from_cur, bool 
     const double t_l0 = now_s();
     if (g_t_last_done > 0) g_t_between += t_l0 - g_t_last_done;
     hipEvent_t *ev = nullptr;
+    uint32_t walk_blocks = 0;
+    bool optimistic = false;
     if (c->timing) {
         if (c->ev_used == symmicp_ctx::kEvRing) flush_events(c);
         ev = c->ev + c->ev_used * symmicp_ctx::kEvPer;
@@ -702,37 +704,42 @@ static int run_pass(symmicp_ctx *c, const float Xapply[16], bool from_cur, bool 
             c->pass_blocks = blocks = ab;
             // Walk grid: any size is correct (the kernel strides over the list); sized from the previous pass's list
             // length, which only shrinks while an alignment converges.  Unknown or long lists get the full grid.
-            uint32_t wb = 0;
             if (!first && c->last_list_len >= 0 && c->last_list_len <= 50000) {
-                wb = (uint32_t)(2 * c->last_list_len);
-                if (wb < 256u) wb = 256u;
-                if (wb > 8192u) wb = 8192u;
+                walk_blocks = (uint32_t)(2 * c->last_list_len);
+                if (walk_blocks < 256u) walk_blocks = 256u;
+                if (walk_blocks > 8192u) walk_blocks = 8192u;
             }
-            if (std::getenv("SYMMICP_WALK_FULL_GRID")) wb = 0;
+            if (std::getenv("SYMMICP_WALK_FULL_GRID")) walk_blocks = 0;
+            // Once an alignment has converged the work list stays empty (every pair is certified or settled by the cell
+            // scan), and an empty walk launch still costs ~6 us of a ~50 us pass.  So after a pass with an empty list the
+            // walk is skipped; the final reduce reports the list's length, and in the rare case that it is not empty
+            // after all the pass is repaired below (walk, accumulate and reduce again).
+            static const char *opt_env = std::getenv("SYMMICP_OPTIMISTIC");      // "0" never, "1" always (tests), unset: auto
+            optimistic = opt_env ? (opt_env[0] == '1') : (!first && c->last_list_len == 0);
+            if (writeback) optimistic = false;      // in-place write-back: a repair would transform the cloud twice
             // per-kernel events only in timing mode 2; mode 1 brackets the pass (events 0 and 4)
-            launch_pass_tree_split(a, c->ix, c->wl, ab, wb, c->stream, c->timing == 2 ? ev : nullptr);
+            launch_pass_tree_split(a, c->ix, c->wl, ab, walk_blocks, optimistic ? 1 : 0, c->stream, c->timing == 2 ? ev : nullptr);
             if (ev && c->timing == 2) c->ev_split[c->ev_used] = 2;
         }
         break;
     }
     if (ev && c->ev_split[c->ev_used] != 2) hipEventRecord(ev[4], c->stream);
-    const unsigned long long seq = ++c->seq;
-    volatile unsigned long long *flag = reinterpret_cast<volatile unsigned long long *>(c->h_sums + kNSum);
-    launch_final_reduce(c->partials, blocks, c->d_sums, c->comm ? nullptr : c->h_sums_dev, c->ticket, seq, c->wl_count, c->ticket + 1, c->stream);
-    if (c->comm) {
-        int r = g_rccl.AllReduce(c->d_sums, c->d_sums, kNSum, kNcclFloat64, kNcclSum, c->comm, c->stream);
-        if (r != 0) return fail(c, SYMMICP_ERR_COMM, std::string("ncclAllReduce: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?"));
-        launch_publish(c->d_sums, c->ticket + 1, c->h_sums_dev, seq, c->stream);
-    }
-    if (ev) {
-        // the final-reduce time is only separated out in per-kernel mode; otherwise event 5 is event 4 again
-        if (c->ev_split[c->ev_used] != 1) hipEventRecord(ev[5], c->stream);
-        c->ev_used++;
-    }
-    // The record arrives in host-mapped memory followed by its sequence number: spin on that word instead of
-    // paying a stream-synchronise wake-up per iteration.  A stuck stream (kernel fault) is caught by the fallback.
     g_t_launch += now_s() - t_l0;
-    {
+    // Final reduce (+ all-reduce over ranks), then wait for the record.  It arrives in host-mapped memory followed by its
+    // sequence number: spin on that word instead of paying a stream-synchronise wake-up per iteration.  A stuck stream
+    // (kernel fault) is caught by the fallback.
+    auto reduce_and_wait = [&](int keep_nonempty) -> int {
+        const unsigned long long seq = ++c->seq;
+        volatile unsigned long long *flag = reinterpret_cast<volatile unsigned long long *>(c->h_sums + kNSum);
+        launch_final_reduce(c->partials, blocks, c->d_sums, c->comm ? nullptr : c->h_sums_dev, c->ticket, seq,
+                            c->cfg.corr == SYMMICP_CORR_TREE ? c->wl_count : nullptr, keep_nonempty, c->stream);
+        if (c->comm) {
+            int r = g_rccl.AllReduce(c->d_sums, c->d_sums, kNSum, kNcclFloat64, kNcclSum, c->comm, c->stream);
+            if (r != 0) return fail(c, SYMMICP_ERR_COMM, std::string("ncclAllReduce: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?"));
+            launch_publish(c->d_sums, c->h_sums_dev, seq, c->stream);
+        }
+        // the final-reduce time is only separated out in per-kernel mode; otherwise event 5 is event 4 again
+        if (ev && c->ev_split[c->ev_used] != 1) hipEventRecord(ev[5], c->stream);
         const double t_spin = now_s();
         unsigned spins = 0;
         bool got = false;
@@ -744,13 +751,26 @@ static int run_pass(symmicp_ctx *c, const float Xapply[16], bool from_cur, bool 
             }
         }
         __atomic_thread_fence(__ATOMIC_ACQUIRE);
-        g_t_spin += now_s() - t_spin; g_t_last_done = now_s(); g_n_pass++;
+        g_t_spin += now_s() - t_spin;
         if (!got) {
             HIP_TRY(c, hipStreamSynchronize(c->stream));
             HIP_TRY(c, hipGetLastError());
             if (*flag != seq) return fail(c, SYMMICP_ERR_HIP, "pass finished without publishing its record");
         }
+        return SYMMICP_OK;
+    };
+    if (int st = reduce_and_wait(optimistic ? 1 : 0)) return st;
+    // length of the work list (summed over ranks by the all-reduce, so every rank takes the same decision)
+    long long list_len = (c->cfg.corr == SYMMICP_CORR_TREE) ? (long long)c->h_sums[kNSum - 1] : -1;
+    if (optimistic && list_len > 0) {
+        // the walk was skipped but some queries needed it: their pairs are provisional, so are the sums
+        c->st.kernel_launches[7]++;
+        launch_pass_tree_split(a, c->ix, c->wl, blocks, list_len <= 50000 ? 8192u : 0u, 2, c->stream, nullptr);
+        if (ev && c->ev_split[c->ev_used] != 2) hipEventRecord(ev[4], c->stream);
+        if (int st = reduce_and_wait(0)) return st;
     }
+    if (ev) c->ev_used++;
+    g_t_last_done = now_s(); g_n_pass++;
     if (c->ix.dbg) {
         unsigned long long h[8];
         hipMemcpy(h, c->ix.dbg, sizeof(h), hipMemcpyDeviceToHost);
@@ -759,7 +779,8 @@ static int run_pass(symmicp_ctx *c, const float Xapply[16], bool from_cur, bool 
                      (long long)c->st.passes, h[1], h[2], h[6], h[7], h[0], h[3], h[4], h[5]);
     }
     std::memcpy(c->last.s, c->h_sums, sizeof(double) * kNSum);
-    c->last_list_len = (c->cfg.corr == SYMMICP_CORR_TREE) ? (long long)reinterpret_cast<volatile unsigned long long *>(c->h_sums)[kNSum + 1] : -1;
+    if (c->cfg.corr == SYMMICP_CORR_TREE) c->last.s[kNSum - 1] = 0.0;      // that slot carried the list length, not a sum
+    c->last_list_len = list_len;
     c->st.passes++;
     return SYMMICP_OK;
 }

@@ -1001,7 +1001,7 @@ __global__ __launch_bounds__(kPassThreads) void k_accumulate(PassArgs a, const f
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_final_reduce(const double *__restrict__ partials, int nblocks,
                                                       double *out_dev, double *out_host, uint32_t *ticket,
-                                                      unsigned long long seq, uint32_t *counters_to_clear, uint32_t *list_len_dev)
+                                                      unsigned long long seq, uint32_t *counters_to_clear, int keep_nonempty)
 {
     __shared__ double red[256];
     const int k = blockIdx.x, t = threadIdx.x;
@@ -1025,18 +1025,25 @@ __global__ __launch_bounds__(256) void k_final_reduce(const double *__restrict__
     }
     __syncthreads();
     if (last) {
-        // shard counters of the pass's append lists: report the work list's length (it sizes the next pass's walk
-        // grid), then zero them for the next pass
+        // Shard counters of the pass's append lists.  The work list's length travels in the record's last slot (unused
+        // by the sums; with several GPUs the all-reduce turns it into the total over ranks): it sizes the next pass's
+        // walk grid and tells the host whether a pass that skipped the walk has to be repaired.  The counters are
+        // zeroed for the next pass -- unless this pass skipped the walk and the list turned out non-empty.
         if (counters_to_clear) {
+            __shared__ uint32_t s_len;
             if (t < 64) {
                 uint32_t v = counters_to_clear[t * kShardStride];
 #pragma unroll
                 for (int off = 32; off > 0; off >>= 1) v += (uint32_t)__shfl_xor((int)v, off, 64);
-                if (t == 0 && out_host) reinterpret_cast<volatile unsigned long long *>(out_host)[kNSum + 1] = v;
-                if (t == 0) *list_len_dev = v;
+                if (t == 0) {
+                    s_len = v;
+                    out_dev[kNSum - 1] = (double)v;
+                    if (out_host) out_host[kNSum - 1] = (double)v;
+                }
             }
             __syncthreads();
-            for (int c = t; c < 3 * kShards; c += 256) counters_to_clear[c * kShardStride] = 0;
+            if (!(keep_nonempty && s_len > 0u))
+                for (int c = t; c < 3 * kShards; c += 256) counters_to_clear[c * kShardStride] = 0;
         }
         if (t == 0) {
             *ticket = 0;
@@ -1049,11 +1056,9 @@ __global__ __launch_bounds__(256) void k_final_reduce(const double *__restrict__
 }
 
 // multi-GPU: after the RCCL all-reduce, copy the record to host-mapped memory and publish the sequence number
-__global__ __launch_bounds__(64) void k_publish(const double *__restrict__ sums_dev, const uint32_t *__restrict__ list_len_dev,
-                                                double *out_host, unsigned long long seq)
+__global__ __launch_bounds__(64) void k_publish(const double *__restrict__ sums_dev, double *out_host, unsigned long long seq)
 {
     if (threadIdx.x < kNSum) out_host[threadIdx.x] = sums_dev[threadIdx.x];
-    if (threadIdx.x == 0) reinterpret_cast<volatile unsigned long long *>(out_host)[kNSum + 1] = *list_len_dev;
     __threadfence_system();
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -1163,34 +1168,38 @@ uint32_t walk_blocks_full(const WorkLists &wl)
     return kShards * (wl.work.cap / kWalkThreads);      // one thread per possible list entry
 }
 
+// stage: 0 = whole pass (cells, walk, accumulate); 1 = cells and accumulate only (the host expects an empty work list
+// and repairs the pass otherwise); 2 = the repair: walk and accumulate
 void launch_pass_tree_split(const PassArgs &a, const TargetIndex &ix, const WorkLists &wl, int acc_blocks, uint32_t walk_blocks,
-                            hipStream_t s, hipEvent_t *ev)
+                            int stage, hipStream_t s, hipEvent_t *ev)
 {
     static const uint32_t wave_mode_max = getenv("SYMMICP_WAVE_MODE_MAX") ? (uint32_t)atol(getenv("SYMMICP_WAVE_MODE_MAX")) : 200000u;   // work lists longer than this use one thread per query
     // all shard counters are zero here: cleared by the previous pass's final reduce
     const uint32_t nb = (a.n + kPassThreads - 1) / kPassThreads;
     const uint32_t nbp = ((nb + 7u) / 8u) * 8u;
     if (ev) hipEventRecord(ev[0], s);
-    hipLaunchKernelGGL(k_search_cells, dim3(nbp), dim3(kPassThreads), 0, s, a, ix, wl);
+    if (stage != 2) hipLaunchKernelGGL(k_search_cells, dim3(nbp), dim3(kPassThreads), 0, s, a, ix, wl);
     if (ev) hipEventRecord(ev[1], s);
     if (ev) hipEventRecord(ev[2], s);
-    if (walk_blocks == 0 || walk_blocks > walk_blocks_full(wl)) walk_blocks = walk_blocks_full(wl);
-    hipLaunchKernelGGL(k_search_walk, dim3(walk_blocks), dim3(kWalkThreads), 0, s, a, ix, wl, wave_mode_max);
+    if (stage != 1) {
+        if (walk_blocks == 0 || walk_blocks > walk_blocks_full(wl)) walk_blocks = walk_blocks_full(wl);
+        hipLaunchKernelGGL(k_search_walk, dim3(walk_blocks), dim3(kWalkThreads), 0, s, a, ix, wl, wave_mode_max);
+    }
     if (ev) hipEventRecord(ev[3], s);
     hipLaunchKernelGGL(k_accumulate, dim3(acc_blocks), dim3(kPassThreads), 0, s, a, ix.tq, ix.tn);
     if (ev) hipEventRecord(ev[4], s);
 }
 
 void launch_final_reduce(const double *partials, int blocks, double *out_dev, double *out_host_mapped, uint32_t *ticket,
-                         unsigned long long seq, uint32_t *counters_to_clear, uint32_t *list_len_dev, hipStream_t s)
+                         unsigned long long seq, uint32_t *counters_to_clear, int keep_nonempty, hipStream_t s)
 {
     hipLaunchKernelGGL(k_final_reduce, dim3(kNSum), dim3(256), 0, s, partials, blocks, out_dev, out_host_mapped, ticket, seq,
-                       counters_to_clear, list_len_dev);
+                       counters_to_clear, keep_nonempty);
 }
 
-void launch_publish(const double *sums_dev, const uint32_t *list_len_dev, double *out_host_mapped, unsigned long long seq, hipStream_t s)
+void launch_publish(const double *sums_dev, double *out_host_mapped, unsigned long long seq, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, s, sums_dev, list_len_dev, out_host_mapped, seq);
+    hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, s, sums_dev, out_host_mapped, seq);
 }
 
 void launch_nn_brute(const CloudSoA &src, uint32_t n_s, const Affine &X, const float4 *tq, uint32_t n_t,

@@ -109,13 +109,15 @@ void launch_pass_identity(const PassArgs &a, CloudSoA tgt, int blocks, bool vec4
 void launch_pass_indexed(const PassArgs &a, const float4 *tq, const float4 *tn, int blocks, hipStream_t s);
 // ev: null, or 5 events recorded before cells / after cells / (same again) / after walk / after accumulate
 // walk_blocks: grid of k_search_walk (any size is correct; 0 = one thread per possible list entry)
+// stage: 0 = cells, walk, accumulate; 1 = cells, accumulate (walk skipped); 2 = walk, accumulate (repair of a stage-1 pass)
 void launch_pass_tree_split(const PassArgs &a, const TargetIndex &ix, const WorkLists &wl, int acc_blocks, uint32_t walk_blocks,
-                            hipStream_t s, hipEvent_t *ev);
+                            int stage, hipStream_t s, hipEvent_t *ev);
 uint32_t walk_blocks_full(const WorkLists &wl);
 uint32_t shard_capacity(uint32_t n_points);
+// keep_nonempty: leave the append-list counters alone when the work list is not empty (stage-1 passes)
 void launch_final_reduce(const double *partials, int blocks, double *out_dev, double *out_host_mapped, uint32_t *ticket,
-                         unsigned long long seq, uint32_t *counters_to_clear, uint32_t *list_len_dev, hipStream_t s);
-void launch_publish(const double *sums_dev, const uint32_t *list_len_dev, double *out_host_mapped, unsigned long long seq, hipStream_t s);
+                         unsigned long long seq, uint32_t *counters_to_clear, int keep_nonempty, hipStream_t s);
+void launch_publish(const double *sums_dev, double *out_host_mapped, unsigned long long seq, hipStream_t s);
 void launch_nn_brute(const CloudSoA &src, uint32_t n_s, const Affine &X, const float4 *tq, uint32_t n_t,
                      unsigned long long *best64, hipStream_t s);
 

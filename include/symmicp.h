@@ -192,7 +192,8 @@ typedef struct {
     /* per-kernel HIP-event time since the last reset (timing mode), slots:
      * 0 k_search_cells, 1 idle gap between cells and walk, 2 k_search_walk, 3 k_accumulate, 4 k_final_reduce,
      * 5 the single pass kernel of the IDENTITY / BRUTE modes (k_pass_identity, or k_nn_brute + k_pass_indexed),
-     * 6 the whole pass bracketed by two events (timing mode 1) */
+     * 6 the whole pass bracketed by two events (timing mode 1);
+     * kernel_launches[7] counts passes that skipped the tree walk and had to be repaired */
     double kernel_ms[8];
     int64_t kernel_launches[8];
 } symmicp_stats;
