@@ -97,7 +97,7 @@ struct symmicp_ctx {
     float *d2 = nullptr;
     float *cert = nullptr;           // TREE: ref_x, ref_y, ref_z, slack (4 planar arrays)
     unsigned long long *best64 = nullptr;
-    uint32_t *worklist = nullptr, *wl_count = nullptr;   // 3 sharded lists + their counters
+    uint32_t *worklist = nullptr, *wl_count = nullptr;   // the sharded work list + its counters
     WorkLists wl{};
     // reduction
     int pass_blocks = 0;
@@ -594,13 +594,10 @@ int symmicp_set_source(symmicp_ctx *c, const float *xyz, size_t xr, size_t xc, c
         HIP_TRY(c, hipMemset(c->cert, 0, sizeof(float) * 4 * nl));
         const uint32_t cap = shard_capacity(nl);
         const size_t per_list = (size_t)kShards * cap, ncount = (size_t)kShards * kShardStride;
-        HIP_TRY(c, hipMalloc((void **)&c->worklist, sizeof(uint32_t) * 3 * per_list));      // work, overflow, medium
-        HIP_TRY(c, hipMalloc((void **)&c->wl_count, sizeof(uint32_t) * 3 * ncount));
-        HIP_TRY(c, hipMemset(c->wl_count, 0, sizeof(uint32_t) * 3 * ncount));
+        HIP_TRY(c, hipMalloc((void **)&c->worklist, sizeof(uint32_t) * per_list));
+        HIP_TRY(c, hipMalloc((void **)&c->wl_count, sizeof(uint32_t) * ncount));
+        HIP_TRY(c, hipMemset(c->wl_count, 0, sizeof(uint32_t) * ncount));
         c->wl.work = ShardList{c->worklist, c->wl_count, cap};
-        c->wl.overflow = ShardList{c->worklist + per_list, c->wl_count + ncount, cap};
-        c->wl.medium = ShardList{c->worklist + 2 * per_list, c->wl_count + 2 * ncount, cap};
-        c->wl.all_counts = c->wl_count;
     }
     HIP_TRY(c, hipGetLastError());
     c->st.upload_ms += (now_s() - t0) * 1e3;

@@ -77,8 +77,7 @@ struct ShardList {
     uint32_t cap;
 };
 struct WorkLists {
-    ShardList work, overflow, medium;
-    uint32_t *all_counts;                 // the three counter blocks, contiguous: cleared by the final reduce
+    ShardList work;                       // queries k_search_cells hands to k_search_walk; counters cleared by the final reduce
 };
 
 struct PassArgs {

@@ -417,6 +417,34 @@ def test_c4_1m_properties(sym, oracle):
     assert r["diff_final"] < 0.2 * r["diff_initial"]
 
 
+def test_8m_surface_properties(sym, oracle):
+    """BASELINE's largest size (C5: 8M/8M) on the fast C4-style generator (the ray-cast C5 generator needs minutes of
+    host time): the size-dependent machinery -- 8M-key radix sorts, 31k-block grids, level-10 cell table -- must still
+    give the exact nearest neighbour and a record that matches a host recomputation from the returned pairs."""
+    from symmicp import synth
+    n = 8_000_000
+    d = synth.c4_surface(n)
+    with sym.Engine(mode=sym.MODE_PAPER, corr=sym.CORR_TREE, max_iters=12, fixed_iters=1) as e:
+        e.set_target(d["tgt"], d["tgt_n"])
+        e.set_source(d["src"], d["src_n"])
+        it0 = e.begin()
+        idx, d2 = e.correspondences()
+        rng = np.random.default_rng(1)
+        sub = rng.choice(n, 20000, replace=False)
+        ri, rd = oracle.nn_grid(d["src"][sub], d["tgt"])
+        assert np.array_equal(idx[sub], ri) and np.array_equal(d2[sub], rd)
+        S = oracle.reduce40(d["src"], d["src_n"], d["tgt"], d["tgt_n"], idx=idx, pivot=e.pivot())
+        _sums_close(it0["sums"], S, 1e-10)
+        assert it0["sums"][34] == n
+        r = e.align()
+        # after 12 iterations the pairs are still the exact nearest neighbours of the moved cloud (certificates included)
+        idx, d2 = e.correspondences()
+        ri, rd = oracle.nn_grid(d["src"][sub], d["tgt"], X=r["transform"])     # (the last pass ran under the final transform)
+        assert np.array_equal(idx[sub], ri) and np.array_equal(d2[sub], rd)
+    assert r["status"] == 0 and r["iters"] == 12
+    assert np.abs(r["transform"] - d["truth"]).max() < 2e-4
+
+
 def test_cpp_driver_prints_the_reference_lines(cat, tmp_path):
     """examples/main.cpp (the reference's ICP/main.cpp call sequence) through the C++ MyICP class:
     stdout carries the reference's lines (myicp.cpp:125-126,146-149) and the oracle's numbers."""
