@@ -519,7 +519,7 @@ int symmicp_set_target(symmicp_ctx *c, const float *xyz, size_t xr, size_t xc, c
 
     const double t1 = now_s();
     HIP_TRY(c, hipMalloc((void **)&c->tq, sizeof(float4) * n));
-    HIP_TRY(c, hipMalloc((void **)&c->tn, sizeof(float4) * n));
+    HIP_TRY(c, hipMalloc((void **)&c->tn, sizeof(float4) * 2 * n));      // (point, normal) pair records
     if (c->cfg.corr == SYMMICP_CORR_BRUTE) {
         launch_iota_f4(c->tgt.x, c->tgt.y, c->tgt.z, c->tgt.nx, c->tgt.ny, c->tgt.nz, c->n_t, c->tq, c->tn, c->stream);
         HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -689,7 +689,7 @@ static int run_pass(symmicp_ctx *c, const float Xapply[16], bool from_cur, bool 
     }
     case SYMMICP_CORR_BRUTE:
         launch_nn_brute(a.in, c->n_loc, a.X, c->tq, c->n_t, c->best64, c->stream);
-        launch_pass_indexed(a, c->tq, c->tn, blocks, c->stream);
+        launch_pass_indexed(a, c->tn, blocks, c->stream);
         break;
     default:
         {
@@ -1000,7 +1000,7 @@ int symmicp_estimate_normals(int device, const float *xyz, size_t row_stride, si
     CloudSoA cl;
     soa_from_block(block, n, cl);
     TargetIndex ix{};
-    bool ok = hipMalloc((void **)&tq, sizeof(float4) * n) == hipSuccess && hipMalloc((void **)&tn, sizeof(float4) * n) == hipSuccess &&
+    bool ok = hipMalloc((void **)&tq, sizeof(float4) * n) == hipSuccess && hipMalloc((void **)&tn, sizeof(float4) * 2 * n) == hipSuccess &&
               hipMalloc((void **)&d_nrm, sizeof(float) * 3 * n) == hipSuccess && hipMalloc((void **)&d_curv, sizeof(float) * n) == hipSuccess;
     if (!ok) { cleanup(); return SYMMICP_ERR_HIP; }
     st = build_index(c, cl, (uint32_t)n, /*want_grid=*/false, tq, tn, &boxes, &cells, &ix, nullptr, nullptr);

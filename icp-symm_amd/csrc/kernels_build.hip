@@ -211,8 +211,11 @@ __global__ __launch_bounds__(256) void k_gather_f4(const float *__restrict__ x, 
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     uint32_t j = order ? order[i] : i;
-    tq[i] = make_float4(x[j], y[j], z[j], __int_as_float((int)j));
-    tn[i] = make_float4(nx[j], ny[j], nz[j], 0.0f);
+    const float4 q = make_float4(x[j], y[j], z[j], __int_as_float((int)j));
+    tq[i] = q;
+    // tn holds 32-byte pair records (point, normal): the accumulating kernels gather both halves from one half-line
+    tn[2 * (size_t)i] = q;
+    tn[2 * (size_t)i + 1] = make_float4(nx[j], ny[j], nz[j], 0.0f);
 }
 
 __global__ __launch_bounds__(256) void k_gather_soa(CloudSoA src, const uint32_t *__restrict__ order, uint32_t n, CloudSoA dst)

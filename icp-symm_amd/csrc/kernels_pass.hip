@@ -218,8 +218,7 @@ __global__ __launch_bounds__(kPassThreads) void k_pass_identity(PassArgs a, Clou
 // pass, pairs given by a previous search kernel (brute force): best64[i] holds
 // (d2 bits << 32 | target row).  Target rows are gathered as float4.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(kPassThreads) void k_pass_indexed(PassArgs a, const float4 *__restrict__ tq,
-                                                              const float4 *__restrict__ tn)
+__global__ __launch_bounds__(kPassThreads) void k_pass_indexed(PassArgs a, const float4 *__restrict__ tn)
 {
     Acc acc; acc_zero(acc);
     const uint32_t stride = gridDim.x * blockDim.x;
@@ -241,7 +240,7 @@ __global__ __launch_bounds__(kPassThreads) void k_pass_indexed(PassArgs a, const
         if (a.d2_out) a.d2_out[i] = ok ? d2 : __int_as_float(0x7f800000);
         if (!ok) continue;
         if (a.max_d2 > 0.0f && d2 > a.max_d2) continue;
-        float4 q = tq[j], nq = tn[j];
+        const float4 q = tn[2 * (size_t)j], nq = tn[2 * (size_t)j + 1];     // one 32-byte pair record
         if (a.min_ndot > -1.0f && (npx * nq.x + npy * nq.y) + npz * nq.z < a.min_ndot) continue;
         acc_pair(acc, px, py, pz, npx, npy, npz, q.x, q.y, q.z, nq.x, nq.y, nq.z, d2, a.pivot, a.p2p);
     }
@@ -965,7 +964,7 @@ __global__ __launch_bounds__(kWalkThreads, 6) void k_search_walk(PassArgs a, Tar
 // The pair's distance is recomputed from the gathered q (bit-identical to the stored one) instead of being read.
 // (A 4-points-per-thread variant with 16-byte column loads was measured and is no faster: the two 16-byte gathers per
 // pair bound this kernel, not the column loads.  Few blocks are: each one ends in a 40-value block reduction.)
-__global__ __launch_bounds__(kPassThreads) void k_accumulate(PassArgs a, const float4 *__restrict__ tq, const float4 *__restrict__ tn)
+__global__ __launch_bounds__(kPassThreads) void k_accumulate(PassArgs a, const float4 *__restrict__ tn)
 {
     Acc acc; acc_zero(acc);
     const uint32_t nbp = gridDim.x;
@@ -985,7 +984,7 @@ __global__ __launch_bounds__(kPassThreads) void k_accumulate(PassArgs a, const f
             a.out.nx[i] = npx; a.out.ny[i] = npy; a.out.nz[i] = npz;
         }
         if (pos < 0) continue;
-        const float4 q = tq[pos], nq = tn[pos];
+        const float4 q = tn[2 * (size_t)pos], nq = tn[2 * (size_t)pos + 1];     // one 32-byte pair record
         const float d2 = dist2(px, py, pz, q.x, q.y, q.z);
         if (a.max_d2 > 0.0f && d2 > a.max_d2) continue;
         if (a.min_ndot > -1.0f && (npx * nq.x + npy * nq.y) + npz * nq.z < a.min_ndot) continue;
@@ -1150,9 +1149,9 @@ void launch_pass_identity(const PassArgs &a, CloudSoA tgt, int blocks, bool vec4
     else hipLaunchKernelGGL(k_pass_identity<1>, dim3(blocks), dim3(kPassThreads), 0, s, a, tgt);
 }
 
-void launch_pass_indexed(const PassArgs &a, const float4 *tq, const float4 *tn, int blocks, hipStream_t s)
+void launch_pass_indexed(const PassArgs &a, const float4 *tn, int blocks, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_pass_indexed, dim3(blocks), dim3(kPassThreads), 0, s, a, tq, tn);
+    hipLaunchKernelGGL(k_pass_indexed, dim3(blocks), dim3(kPassThreads), 0, s, a, tn);
 }
 
 uint32_t shard_capacity(uint32_t n_points)
@@ -1186,7 +1185,7 @@ void launch_pass_tree_split(const PassArgs &a, const TargetIndex &ix, const Work
         hipLaunchKernelGGL(k_search_walk, dim3(walk_blocks), dim3(kWalkThreads), 0, s, a, ix, wl, wave_mode_max);
     }
     if (ev) hipEventRecord(ev[3], s);
-    hipLaunchKernelGGL(k_accumulate, dim3(acc_blocks), dim3(kPassThreads), 0, s, a, ix.tq, ix.tn);
+    hipLaunchKernelGGL(k_accumulate, dim3(acc_blocks), dim3(kPassThreads), 0, s, a, ix.tn);
     if (ev) hipEventRecord(ev[4], s);
 }
 

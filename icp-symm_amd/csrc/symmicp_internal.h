@@ -37,7 +37,7 @@ struct CloudSoA {
 // runs of the sorted order (the "linear BVH").
 struct TargetIndex {
     const float4 *tq;        // sorted: xyz + original row (int bits) in w
-    const float4 *tn;        // sorted: normal xyz, w = 0
+    const float4 *tn;        // sorted, 2 per point: (xyz + original row, normal xyz + 0) -- the 32-byte pair record of the accumulating kernels
     uint32_t n;
     // tree: 2 float4 per node (lo, hi); level l starts at node level_off[l]
     const float4 *boxes;
@@ -105,7 +105,7 @@ struct PassArgs {
 
 // ---- kernel launchers (kernels.hip) ---------------------------------------
 void launch_pass_identity(const PassArgs &a, CloudSoA tgt, int blocks, bool vec4_ok, hipStream_t s);
-void launch_pass_indexed(const PassArgs &a, const float4 *tq, const float4 *tn, int blocks, hipStream_t s);
+void launch_pass_indexed(const PassArgs &a, const float4 *tn /* pair records */, int blocks, hipStream_t s);
 // ev: null, or 5 events recorded before cells / after cells / (same again) / after walk / after accumulate
 // walk_blocks: grid of k_search_walk (any size is correct; 0 = one thread per possible list entry)
 // stage: 0 = cells, walk, accumulate; 1 = cells, accumulate (walk skipped); 2 = walk, accumulate (repair of a stage-1 pass)
