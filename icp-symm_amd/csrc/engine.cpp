@@ -3,8 +3,9 @@
 // Host C++ owns control flow and the 6x6 / 3x3 solve (host_solve.cpp); the GPU owns
 // every O(N) pass (kernels_pass.hip) and the one-time index build (kernels_build.hip).
 // Per iteration of the reference loop (ICP/myicp.cpp:123-142) the host does:
-//   solve(last sums) -> 4x4 increment -> launch ONE fused pass kernel + a 1-block final
-//   reduce -> [RCCL all-reduce of 40 doubles when sharded] -> read 40 doubles -> repeat.
+//   solve(last sums) -> 4x4 increment -> launch the pass (one streaming kernel for identity pairing; search + accumulate
+//   kernels for the nearest-neighbour modes) + the final reduce -> [RCCL all-reduce of 40 doubles when sharded] ->
+//   spin on the record's sequence word in host-mapped memory -> repeat.
 // There is no CPU fallback: without a HIP device every entry point fails loudly.
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
@@ -85,6 +86,7 @@ struct symmicp_ctx {
     float4 *onodes = nullptr;
     uint2 *cells = nullptr;
     uint32_t *ctop = nullptr;
+    unsigned long long *dbg = nullptr;   // debug counters (SYMMICP_DEBUG_COUNTERS)
     TargetIndex ix{};
     bool have_index = false;
     float pivot[3] = {0, 0, 0};
@@ -118,6 +120,18 @@ struct symmicp_ctx {
     int ev_split[kEvRing] = {};      // 1 = split TREE pass (5 kernels), 0 = single pass kernel
     int ev_used = 0;
     symmicp_stats st{};
+};
+
+// temporary device allocation, freed on every exit path (release() hands the pointer over to the context)
+template <typename T>
+struct DevBuf {
+    T *p = nullptr;
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    ~DevBuf() { if (p) hipFree(p); }
+    hipError_t alloc(size_t count) { return hipMalloc((void **)&p, sizeof(T) * (count ? count : 1)); }
+    T *release() { T *q = p; p = nullptr; return q; }
 };
 
 #define HIP_TRY(ctx, call)                                                                                  \
@@ -225,8 +239,8 @@ int symmicp_create(const symmicp_config *cfg, symmicp_ctx **out)
 
 static void free_target(symmicp_ctx *c)
 {
-    hipFree(c->tgt_block); hipFree(c->tq); hipFree(c->tn); hipFree(c->boxes); hipFree(c->cells); hipFree(c->onodes); hipFree(c->ctop);
-    c->ctop = nullptr; c->tgt_block = nullptr; c->tq = nullptr; c->tn = nullptr; c->boxes = nullptr; c->cells = nullptr; c->onodes = nullptr;
+    hipFree(c->tgt_block); hipFree(c->tq); hipFree(c->tn); hipFree(c->boxes); hipFree(c->cells); hipFree(c->onodes); hipFree(c->ctop); hipFree(c->dbg);
+    c->ctop = nullptr; c->dbg = nullptr; c->ix = TargetIndex{}; c->tgt_block = nullptr; c->tq = nullptr; c->tn = nullptr; c->boxes = nullptr; c->cells = nullptr; c->onodes = nullptr;
     c->have_index = false; c->n_t = 0;
 }
 
@@ -306,37 +320,33 @@ static float ord2f(uint32_t o)
 static int morton_order(symmicp_ctx *c, const CloudSoA &cl, uint32_t n, uint32_t **order_out, uint32_t **keys_out,
                         float origin[3], float *h0_out)
 {
-    uint32_t *bbox = nullptr, *keys = nullptr, *vals = nullptr, *kt = nullptr, *vt = nullptr, *ws = nullptr;
+    DevBuf<uint32_t> bbox, keys, vals, kt, vt, ws;
     const size_t wse = radix_sort_ws_elems(n);
-    HIP_TRY(c, hipMalloc((void **)&bbox, 6 * sizeof(uint32_t)));
-    HIP_TRY(c, hipMalloc((void **)&keys, sizeof(uint32_t) * n));
-    HIP_TRY(c, hipMalloc((void **)&vals, sizeof(uint32_t) * n));
-    HIP_TRY(c, hipMalloc((void **)&kt, sizeof(uint32_t) * n));
-    HIP_TRY(c, hipMalloc((void **)&vt, sizeof(uint32_t) * n));
-    HIP_TRY(c, hipMalloc((void **)&ws, sizeof(uint32_t) * wse));
-    launch_bbox(cl.x, cl.y, cl.z, n, bbox, c->stream);
+    HIP_TRY(c, bbox.alloc(6));
+    HIP_TRY(c, keys.alloc(n));
+    HIP_TRY(c, vals.alloc(n));
+    HIP_TRY(c, kt.alloc(n));
+    HIP_TRY(c, vt.alloc(n));
+    HIP_TRY(c, ws.alloc(wse));
+    launch_bbox(cl.x, cl.y, cl.z, n, bbox.p, c->stream);
     uint32_t hb[6];
-    HIP_TRY(c, hipMemcpyAsync(hb, bbox, sizeof(hb), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(hb, bbox.p, sizeof(hb), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     float lo[3], hi[3];
     for (int k = 0; k < 3; k++) { lo[k] = ord2f(hb[k]); hi[k] = ord2f(hb[3 + k]); }
     float emax = 0.f;
     for (int k = 0; k < 3; k++) {
-        if (!std::isfinite(lo[k]) || !std::isfinite(hi[k])) {
-            hipFree(bbox); hipFree(keys); hipFree(vals); hipFree(kt); hipFree(vt); hipFree(ws);
-            return fail(c, SYMMICP_ERR_ARG, "cloud has non-finite coordinates");
-        }
+        if (!std::isfinite(lo[k]) || !std::isfinite(hi[k])) return fail(c, SYMMICP_ERR_ARG, "cloud has non-finite coordinates");
         emax = std::fmax(emax, hi[k] - lo[k]);
     }
     if (!(emax > 0.f)) emax = 1.f;
     const float h0 = emax * 1.00001f / (float)(1 << kMortonBits);
-    launch_morton(cl.x, cl.y, cl.z, n, lo[0], lo[1], lo[2], 1.0f / h0, keys, vals, c->stream);
-    radix_sort_pairs(keys, vals, kt, vt, n, 3 * kMortonBits, ws, wse, c->stream);
+    launch_morton(cl.x, cl.y, cl.z, n, lo[0], lo[1], lo[2], 1.0f / h0, keys.p, vals.p, c->stream);
+    radix_sort_pairs(keys.p, vals.p, kt.p, vt.p, n, 3 * kMortonBits, ws.p, wse, c->stream);
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     HIP_TRY(c, hipGetLastError());
-    hipFree(bbox); hipFree(kt); hipFree(vt); hipFree(ws);
-    *order_out = vals;
-    if (keys_out) *keys_out = keys; else hipFree(keys);
+    *order_out = vals.release();
+    if (keys_out) *keys_out = keys.release();
     for (int k = 0; k < 3; k++) origin[k] = lo[k];
     *h0_out = h0;
     return SYMMICP_OK;
@@ -348,18 +358,19 @@ static int morton_order(symmicp_ctx *c, const CloudSoA &cl, uint32_t n, uint32_t
 static int build_octree(symmicp_ctx *c, const uint32_t *keys, const float4 *tq, uint32_t n, float4 **onodes_out, TargetIndex *ix)
 {
     constexpr int NL = kMortonBits + 1;
-    uint32_t *nid = nullptr;                      // [NL][n]: id of the node that starts at point i, per level
-    uint32_t *scan_ws = nullptr;
-    HIP_TRY(c, hipMalloc((void **)&nid, sizeof(uint32_t) * (size_t)NL * n));
-    HIP_TRY(c, hipMalloc((void **)&scan_ws, sizeof(uint32_t) * ((size_t)n / 2048 + 2)));
+    DevBuf<uint32_t> nid;                         // [NL][n]: id of the node that starts at point i, per level
+    DevBuf<uint32_t> scan_ws, first;
+    DevBuf<float4> nodes;
+    HIP_TRY(c, nid.alloc((size_t)NL * n));
+    HIP_TRY(c, scan_ws.alloc((size_t)n / 2048 + 2));
     for (int l = 0; l < NL; l++) {
-        launch_oct_flags(keys, n, l, nid + (size_t)l * n, c->stream);
-        launch_exclusive_scan(nid + (size_t)l * n, n, scan_ws, c->stream);
+        launch_oct_flags(keys, n, l, nid.p + (size_t)l * n, c->stream);
+        launch_exclusive_scan(nid.p + (size_t)l * n, n, scan_ws.p, c->stream);
     }
     // node counts: exclusive scan value at the last point, +1 if the last point starts a node (host checks the keys)
     uint32_t last_excl[NL], kl[2] = {0, 0};
     for (int l = 0; l < NL; l++)
-        HIP_TRY(c, hipMemcpyAsync(&last_excl[l], nid + (size_t)l * n + (n - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(&last_excl[l], nid.p + (size_t)l * n + (n - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
     if (n >= 2) HIP_TRY(c, hipMemcpyAsync(kl, keys + (n - 2), 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     uint32_t cnt[NL];
@@ -372,50 +383,47 @@ static int build_octree(symmicp_ctx *c, const uint32_t *keys, const float4 *tq, 
         total += cnt[l];
     }
     ix->olevel_off[NL] = (uint32_t)total;
-    if (total > 0xFFFFFFull * NL) { hipFree(nid); return fail(c, SYMMICP_ERR_SIZE, "octree too large"); }
     for (int l = 0; l < NL; l++)
         // child_first is a 24-bit field (node word and walk stack word): targets beyond ~16.7M distinct finest cells are refused
-        if (cnt[l] > 0xFFFFFFu) { hipFree(nid); return fail(c, SYMMICP_ERR_SIZE, "octree level exceeds 2^24 nodes (target cloud too large for SYMMICP_CORR_TREE)"); }
-    uint32_t *first = nullptr;
-    float4 *nodes = nullptr;
-    HIP_TRY(c, hipMalloc((void **)&first, sizeof(uint32_t) * (total + 1)));
-    HIP_TRY(c, hipMalloc((void **)&nodes, sizeof(float4) * 2 * total));
+        if (cnt[l] > 0xFFFFFFu) return fail(c, SYMMICP_ERR_SIZE, "octree level exceeds 2^24 nodes (target cloud too large for SYMMICP_CORR_TREE)");
+    HIP_TRY(c, first.alloc(total + 1));
+    HIP_TRY(c, nodes.alloc(2 * total));
     for (int l = 0; l < NL; l++)
-        launch_oct_first(keys, n, l, nid + (size_t)l * n, first + ix->olevel_off[l], c->stream);
+        launch_oct_first(keys, n, l, nid.p + (size_t)l * n, first.p + ix->olevel_off[l], c->stream);
     for (int l = NL - 1; l >= 0; l--) {
         const bool bottom = (l == NL - 1);
-        launch_oct_nodes(l, tq, n, first + ix->olevel_off[l], cnt[l], bottom ? nullptr : nid + (size_t)(l + 1) * n,
-                         bottom ? 0u : cnt[l + 1], bottom ? nullptr : nodes + 2 * (size_t)ix->olevel_off[l + 1],
-                         nodes + 2 * (size_t)ix->olevel_off[l], c->stream);
+        launch_oct_nodes(l, tq, n, first.p + ix->olevel_off[l], cnt[l], bottom ? nullptr : nid.p + (size_t)(l + 1) * n,
+                         bottom ? 0u : cnt[l + 1], bottom ? nullptr : nodes.p + 2 * (size_t)ix->olevel_off[l + 1],
+                         nodes.p + 2 * (size_t)ix->olevel_off[l], c->stream);
     }
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     HIP_TRY(c, hipGetLastError());
-    hipFree(nid); hipFree(first); hipFree(scan_ws);
-    *onodes_out = nodes;
-    ix->onodes = nodes;
+    *onodes_out = nodes.release();
+    ix->onodes = *onodes_out;
     return SYMMICP_OK;
 }
 
+// The outputs (*boxes_out, *cells_out, *onodes_out, *ctop_out) belong to the caller's context as soon as they are set:
+// on failure the caller's free_target() / cleanup releases them.
 static int build_index(symmicp_ctx *c, const CloudSoA &cl, uint32_t n, bool want_grid, float4 *tq, float4 *tn,
                        float4 **boxes_out, uint2 **cells_out, TargetIndex *ix_out, int32_t *glevel_out, int32_t *nlevels_out,
                        float4 **onodes_out = nullptr, uint32_t **ctop_out = nullptr)
 {
-    uint32_t *order = nullptr, *keys = nullptr;
+    DevBuf<uint32_t> order, keys;
     float origin[3], h0;
-    int st = morton_order(c, cl, n, &order, &keys, origin, &h0);
+    int st = morton_order(c, cl, n, &order.p, &keys.p, origin, &h0);
     if (st != SYMMICP_OK) return st;
-    launch_gather_f4(cl.x, cl.y, cl.z, cl.nx, cl.ny, cl.nz, order, n, tq, tn, c->stream);
+    launch_gather_f4(cl.x, cl.y, cl.z, cl.nx, cl.ny, cl.nz, order.p, n, tq, tn, c->stream);
     TargetIndex ix{};
     ix.tq = tq; ix.tn = tn; ix.n = n;
     int glevel = 0;
     if (want_grid) {
-        uint32_t *hist = nullptr;
-        HIP_TRY(c, hipMalloc((void **)&hist, 16 * sizeof(uint32_t)));
-        launch_level_hist(keys, n, hist, c->stream);
+        DevBuf<uint32_t> hist;
+        HIP_TRY(c, hist.alloc(16));
+        launch_level_hist(keys.p, n, hist.p, c->stream);
         uint32_t hh[16];
-        HIP_TRY(c, hipMemcpyAsync(hh, hist, sizeof(hh), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(hh, hist.p, sizeof(hh), hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
-        hipFree(hist);
         // finest level whose occupied cells still hold >= ppc points on average
         double ppc = 2.0;
         if (const char *e = std::getenv("SYMMICP_GRID_PPC")) ppc = std::atof(e);
@@ -437,14 +445,14 @@ static int build_index(symmicp_ctx *c, const CloudSoA &cl, uint32_t n, bool want
         const int ltop = glevel > 3 ? glevel - 3 : 0;
         const size_t ntop = (size_t)1 << (3 * ltop);
         // block numbers of the occupied super-cells: exclusive scan of their start flags
-        uint32_t *nid_top = nullptr, *scan_ws = nullptr;
-        HIP_TRY(c, hipMalloc((void **)&nid_top, sizeof(uint32_t) * n));
-        HIP_TRY(c, hipMalloc((void **)&scan_ws, sizeof(uint32_t) * ((size_t)n / 2048 + 2)));
-        launch_oct_flags(keys, n, ltop, nid_top, c->stream);
-        launch_exclusive_scan(nid_top, n, scan_ws, c->stream);
+        DevBuf<uint32_t> nid_top, scan_ws;
+        HIP_TRY(c, nid_top.alloc(n));
+        HIP_TRY(c, scan_ws.alloc((size_t)n / 2048 + 2));
+        launch_oct_flags(keys.p, n, ltop, nid_top.p, c->stream);
+        launch_exclusive_scan(nid_top.p, n, scan_ws.p, c->stream);
         uint32_t last_excl = 0, kl[2] = {0, 0};
-        HIP_TRY(c, hipMemcpyAsync(&last_excl, nid_top + (n - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
-        if (n >= 2) HIP_TRY(c, hipMemcpyAsync(kl, keys + (n - 2), 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(&last_excl, nid_top.p + (n - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+        if (n >= 2) HIP_TRY(c, hipMemcpyAsync(kl, keys.p + (n - 2), 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         const int tshift = 3 * (kMortonBits - ltop);
         const bool last_starts = (n == 1) || (tshift < 30 && (kl[1] >> tshift) != (kl[0] >> tshift));
@@ -453,9 +461,8 @@ static int build_index(symmicp_ctx *c, const CloudSoA &cl, uint32_t n, bool want
         HIP_TRY(c, hipMemsetAsync(*ctop_out, 0xFF, sizeof(uint32_t) * ntop, c->stream));
         HIP_TRY(c, hipMalloc((void **)cells_out, sizeof(uint2) * nblocks * 512));
         HIP_TRY(c, hipMemsetAsync(*cells_out, 0, sizeof(uint2) * nblocks * 512, c->stream));
-        launch_cell_table(keys, n, glevel, nid_top, *ctop_out, *cells_out, c->stream);
+        launch_cell_table(keys.p, n, glevel, nid_top.p, *ctop_out, *cells_out, c->stream);
         HIP_TRY(c, hipStreamSynchronize(c->stream));
-        hipFree(nid_top); hipFree(scan_ws);
         ix.ctop = *ctop_out;
         ix.cells = *cells_out;
         ix.gdim = 1 << glevel;
@@ -476,7 +483,7 @@ static int build_index(symmicp_ctx *c, const CloudSoA &cl, uint32_t n, bool want
         nl++;
         if (m <= (uint32_t)kFan) break;
         m = pad[nl - 1] / kFan;
-        if (nl >= kMaxTreeLevels) { hipFree(order); hipFree(keys); return fail(c, SYMMICP_ERR_SIZE, "tree too deep"); }
+        if (nl >= kMaxTreeLevels) return fail(c, SYMMICP_ERR_SIZE, "tree too deep");
     }
     ix.top = nl - 1;
     ix.ntop = cnt[nl - 1];
@@ -489,10 +496,9 @@ static int build_index(symmicp_ctx *c, const CloudSoA &cl, uint32_t n, bool want
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     HIP_TRY(c, hipGetLastError());
     if (onodes_out) {
-        st = build_octree(c, keys, tq, n, onodes_out, &ix);
-        if (st != SYMMICP_OK) { hipFree(order); hipFree(keys); return st; }
+        st = build_octree(c, keys.p, tq, n, onodes_out, &ix);
+        if (st != SYMMICP_OK) return st;
     }
-    hipFree(order); hipFree(keys);
     *ix_out = ix;
     if (glevel_out) *glevel_out = glevel;
     if (nlevels_out) *nlevels_out = nl;
@@ -528,12 +534,11 @@ int symmicp_set_target(symmicp_ctx *c, const float *xyz, size_t xr, size_t xc, c
     }
     st = build_index(c, c->tgt, c->n_t, /*want_grid=*/true, c->tq, c->tn, &c->boxes, &c->cells, &c->ix, &c->st.grid_level, &c->st.tree_levels,
                      &c->onodes, &c->ctop);
-    if (st != SYMMICP_OK) return st;
+    if (st != SYMMICP_OK) { free_target(c); return st; }
     if (std::getenv("SYMMICP_DEBUG_COUNTERS")) {
-        unsigned long long *dbg = nullptr;
-        HIP_TRY(c, hipMalloc((void **)&dbg, 8 * sizeof(unsigned long long)));
-        HIP_TRY(c, hipMemset(dbg, 0, 8 * sizeof(unsigned long long)));
-        c->ix.dbg = dbg;
+        HIP_TRY(c, hipMalloc((void **)&c->dbg, 8 * sizeof(unsigned long long)));
+        HIP_TRY(c, hipMemset(c->dbg, 0, 8 * sizeof(unsigned long long)));
+        c->ix.dbg = c->dbg;
     }
     c->have_index = true;
     c->st.build_ms = (now_s() - t1) * 1e3;
@@ -549,11 +554,11 @@ int symmicp_set_source(symmicp_ctx *c, const float *xyz, size_t xr, size_t xc, c
     const double t0 = now_s();
     free_source(c);
     c->begun = false;
-    float *full = nullptr;
-    int st = upload_planar(c, xyz, xr, xc, nrm, nr, nc, n, &full, nullptr);
+    DevBuf<float> full;
+    int st = upload_planar(c, xyz, xr, xc, nrm, nr, nc, n, &full.p, nullptr);
     if (st != SYMMICP_OK) return st;
     CloudSoA fs;
-    soa_from_block(full, n, fs);
+    soa_from_block(full.p, n, fs);
     c->n_s_total = (uint32_t)n;
     // contiguous share of the (sorted) source for this rank
     size_t b0 = 0, bc = 0;
@@ -567,17 +572,16 @@ int symmicp_set_source(symmicp_ctx *c, const float *xyz, size_t xr, size_t xc, c
     soa_from_block(c->cur_block, nl, c->cur);
     const bool sorted = c->cfg.corr != SYMMICP_CORR_IDENTITY && c->cfg.sort_source;
     if (sorted) {
-        uint32_t *order = nullptr;
+        DevBuf<uint32_t> order;
         float origin[3], h0;
-        st = morton_order(c, fs, (uint32_t)n, &order, nullptr, origin, &h0);
-        if (st != SYMMICP_OK) { hipFree(full); return st; }
+        st = morton_order(c, fs, (uint32_t)n, &order.p, nullptr, origin, &h0);
+        if (st != SYMMICP_OK) return st;
         HIP_TRY(c, hipMalloc((void **)&c->src_order, sizeof(uint32_t) * nl));
         if (c->n_loc) {
-            HIP_TRY(c, hipMemcpyAsync(c->src_order, order + b0, sizeof(uint32_t) * c->n_loc, hipMemcpyDeviceToDevice, c->stream));
+            HIP_TRY(c, hipMemcpyAsync(c->src_order, order.p + b0, sizeof(uint32_t) * c->n_loc, hipMemcpyDeviceToDevice, c->stream));
             launch_gather_soa(fs, c->src_order, c->n_loc, c->src0, c->stream);
         }
         HIP_TRY(c, hipStreamSynchronize(c->stream));
-        hipFree(order);
     } else if (c->n_loc) {
         const float *from[6] = {fs.x, fs.y, fs.z, fs.nx, fs.ny, fs.nz};
         float *to[6] = {c->src0.x, c->src0.y, c->src0.z, c->src0.nx, c->src0.ny, c->src0.nz};
@@ -585,7 +589,7 @@ int symmicp_set_source(symmicp_ctx *c, const float *xyz, size_t xr, size_t xc, c
             HIP_TRY(c, hipMemcpyAsync(to[k], from[k] + b0, sizeof(float) * c->n_loc, hipMemcpyDeviceToDevice, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
     }
-    hipFree(full);
+    hipFree(full.release());
     HIP_TRY(c, hipMalloc((void **)&c->pos, sizeof(int32_t) * nl));
     HIP_TRY(c, hipMalloc((void **)&c->d2, sizeof(float) * nl));
     if (c->cfg.corr == SYMMICP_CORR_BRUTE) HIP_TRY(c, hipMalloc((void **)&c->best64, sizeof(unsigned long long) * nl));
@@ -914,12 +918,12 @@ int symmicp_get_correspondences(symmicp_ctx *c, int32_t *idx, float *d2, size_t 
     const size_t need = c->src_order ? c->n_s_total : c->n_loc;
     if (cap < need) return fail(c, SYMMICP_ERR_SIZE, "output too small");
     HIP_TRY(c, hipSetDevice(c->device));
-    int32_t *d_idx = nullptr;
-    float *d_d2 = nullptr;
-    HIP_TRY(c, hipMalloc((void **)&d_idx, sizeof(int32_t) * need));
-    HIP_TRY(c, hipMalloc((void **)&d_d2, sizeof(float) * need));
-    HIP_TRY(c, hipMemsetAsync(d_idx, 0xFF, sizeof(int32_t) * need, c->stream));
-    HIP_TRY(c, hipMemsetAsync(d_d2, 0, sizeof(float) * need, c->stream));
+    DevBuf<int32_t> d_idx;
+    DevBuf<float> d_d2;
+    HIP_TRY(c, d_idx.alloc(need));
+    HIP_TRY(c, d_d2.alloc(need));
+    HIP_TRY(c, hipMemsetAsync(d_idx.p, 0xFF, sizeof(int32_t) * need, c->stream));
+    HIP_TRY(c, hipMemsetAsync(d_d2.p, 0, sizeof(float) * need, c->stream));
     const int mode = c->cfg.corr == SYMMICP_CORR_IDENTITY ? 0 : (c->cfg.corr == SYMMICP_CORR_BRUTE ? 1 : 2);
     if (mode == 0 && d2) {
         // the identity pass streams without storing distances: evaluate them now from the current source positions
@@ -932,11 +936,10 @@ int symmicp_get_correspondences(symmicp_ctx *c, int32_t *idx, float *d2, size_t 
         X.nrm_w = 0.f;
         launch_identity_d2(incr ? c->cur : c->src0, X, c->tgt, c->src_off, c->n_loc, c->d2, c->stream);
     }
-    launch_corr_out(c->pos, c->best64, c->d2, c->tq, c->src_order, c->n_loc, mode, c->src_off, d_idx, d_d2, c->stream);
-    if (idx) HIP_TRY(c, hipMemcpyAsync(idx, d_idx, sizeof(int32_t) * need, hipMemcpyDeviceToHost, c->stream));
-    if (d2) HIP_TRY(c, hipMemcpyAsync(d2, d_d2, sizeof(float) * need, hipMemcpyDeviceToHost, c->stream));
+    launch_corr_out(c->pos, c->best64, c->d2, c->tq, c->src_order, c->n_loc, mode, c->src_off, d_idx.p, d_d2.p, c->stream);
+    if (idx) HIP_TRY(c, hipMemcpyAsync(idx, d_idx.p, sizeof(int32_t) * need, hipMemcpyDeviceToHost, c->stream));
+    if (d2) HIP_TRY(c, hipMemcpyAsync(d2, d_d2.p, sizeof(float) * need, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    hipFree(d_idx); hipFree(d_d2);
     return SYMMICP_OK;
 }
 
@@ -949,16 +952,15 @@ int symmicp_get_source(symmicp_ctx *c, float *xyz, float *nrm, size_t cap)
     const size_t need = c->src_order ? c->n_s_total : c->n_loc;
     if (cap < need) return fail(c, SYMMICP_ERR_SIZE, "output too small");
     HIP_TRY(c, hipSetDevice(c->device));
-    float *dx = nullptr, *dn = nullptr;
-    HIP_TRY(c, hipMalloc((void **)&dx, sizeof(float) * 3 * need));
-    HIP_TRY(c, hipMalloc((void **)&dn, sizeof(float) * 3 * need));
-    HIP_TRY(c, hipMemsetAsync(dx, 0, sizeof(float) * 3 * need, c->stream));
-    HIP_TRY(c, hipMemsetAsync(dn, 0, sizeof(float) * 3 * need, c->stream));
-    launch_unpermute(c->cur, c->src_order, c->n_loc, dx, dn, c->stream);
-    if (xyz) HIP_TRY(c, hipMemcpyAsync(xyz, dx, sizeof(float) * 3 * need, hipMemcpyDeviceToHost, c->stream));
-    if (nrm) HIP_TRY(c, hipMemcpyAsync(nrm, dn, sizeof(float) * 3 * need, hipMemcpyDeviceToHost, c->stream));
+    DevBuf<float> dx, dn;
+    HIP_TRY(c, dx.alloc(3 * need));
+    HIP_TRY(c, dn.alloc(3 * need));
+    HIP_TRY(c, hipMemsetAsync(dx.p, 0, sizeof(float) * 3 * need, c->stream));
+    HIP_TRY(c, hipMemsetAsync(dn.p, 0, sizeof(float) * 3 * need, c->stream));
+    launch_unpermute(c->cur, c->src_order, c->n_loc, dx.p, dn.p, c->stream);
+    if (xyz) HIP_TRY(c, hipMemcpyAsync(xyz, dx.p, sizeof(float) * 3 * need, hipMemcpyDeviceToHost, c->stream));
+    if (nrm) HIP_TRY(c, hipMemcpyAsync(nrm, dn.p, sizeof(float) * 3 * need, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    hipFree(dx); hipFree(dn);
     return SYMMICP_OK;
 }
 
