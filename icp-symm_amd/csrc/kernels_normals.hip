@@ -5,7 +5,8 @@
 //   the tree), their mean and covariance, the eigenvector of the smallest eigenvalue,
 //   flipped so that (viewpoint - p) . n >= 0 (viewpoint defaults to the origin).
 // The k-NN set is exact: (d2, row) lexicographic, found by a pruned pre-order walk of the
-// same implicit 8-ary box tree the correspondence search uses.  Moments are fp64.
+// same implicit 8-ary box tree the correspondence search uses, its radius bounded from the start by
+// the query's neighbours on the Morton curve.  Moments are fp64.
 #include "symmicp_internal.h"
 #pragma clang fp contract(off)
 
@@ -90,6 +91,37 @@ __global__ __launch_bounds__(256) void k_normals_knn(TargetIndex ix, int k, floa
     for (int j = 0; j < kKnnMax; j++) { bd[j] = __int_as_float(0x7f800000); br[j] = 0x7fffffff; bp[j] = -1; }
     const int last = k - 1;
 
+    // Bound from the neighbours in the sorted order: the query is itself a point of the cloud, and the 2k+1 points around
+    // it on the Morton curve are near it in space, so the k-th smallest of their distances bounds the k-th nearest
+    // neighbour's distance from above (only the bound is kept, not the points: the walk finds them again and would
+    // otherwise have to filter duplicates).  Without it the pre-order walk starts at the far end of the cloud with an
+    // infinite radius and prunes nothing until k arbitrary points have been seen.
+    float seed = __int_as_float(0x7f800000);
+    {
+        const uint32_t w = 2u * (uint32_t)k + 1u;
+        uint32_t j1 = min(((i > (uint32_t)k) ? i - (uint32_t)k : 0u) + w, ix.n);
+        uint32_t j0 = (j1 >= w) ? j1 - w : 0u;
+        float sd[kKnnMax];
+#pragma unroll
+        for (int j = 0; j < kKnnMax; j++) sd[j] = __int_as_float(0x7f800000);
+        for (uint32_t jj = j0; jj < j1; jj++) {
+            const float4 q = ix.tq[jj];
+            const float d2 = n_dist2(px, py, pz, q.x, q.y, q.z);
+            float wd = __int_as_float(0x7f800000);
+#pragma unroll
+            for (int j = 0; j < kKnnMax; j++) if (j == last) wd = sd[j];
+            if (d2 < wd) {
+#pragma unroll
+                for (int j = 0; j < kKnnMax; j++) if (j == last) sd[j] = d2;
+#pragma unroll
+                for (int j = kKnnMax - 1; j > 0; j--)
+                    if (j <= last && sd[j] < sd[j - 1]) { const float t = sd[j]; sd[j] = sd[j - 1]; sd[j - 1] = t; }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < kKnnMax; j++) if (j == last) seed = sd[j];
+    }
+
     int level = ix.top;
     uint32_t node = 0;
     while (true) {
@@ -100,7 +132,7 @@ __global__ __launch_bounds__(256) void k_normals_knn(TargetIndex ix, int k, floa
         float worst = __int_as_float(0x7f800000);
 #pragma unroll
         for (int j = 0; j < kKnnMax; j++) if (j == last) worst = bd[j];
-        bool hit = (d <= worst) && (lo.x <= hi.x);
+        bool hit = (d <= fminf(worst, seed)) && (lo.x <= hi.x);
         if (hit && level > 0) { level--; node <<= 3; continue; }
         if (hit) {
             uint32_t j0 = node * kLeaf, j1 = min(j0 + kLeaf, ix.n);
