@@ -158,7 +158,7 @@ def main():
         wk = "%s:%d:%s:%s" % (args.workload, n_s, args.mode, args.corr)
         if world == 1 and wk in tj["workloads"]:
             w = tj["workloads"][wk]
-            traffic = sum(v["hbm_bytes_per_launch"] for k, v in w.items() if not k.startswith("_") and k != "k_final_reduce")
+            traffic = int(w["_whole_pass_hbm_bytes"])       # all kernels of a pass, total bytes / passes
     except Exception:
         pass
     roofline = dict(bound="hbm", achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit="GB/s",
