@@ -77,6 +77,8 @@ struct symmicp_ctx {
     // communicator
     int nranks = 1, rank = 0;
     rcclComm_t comm = nullptr;
+    bool external_exchange = false;  // sharded, but the application sums the records (symmicp_set_sums)
+    bool sums_exchanged = false;     // ... and has done so for the last pass
     // target
     uint32_t n_t = 0;
     float *tgt_block = nullptr;      // 6 planar arrays
@@ -821,6 +823,7 @@ int symmicp_begin(symmicp_ctx *c, const float *guess16, symmicp_iter_result *out
     st = run_pass(c, c->X, /*from_cur=*/false, /*writeback=*/incr, /*first=*/true);
     if (st != SYMMICP_OK) return st;
     c->begun = true;
+    c->sums_exchanged = false;
     fill_iter(c, out, SYMMICP_OK, 1.0f, nullptr);
     return SYMMICP_OK;
 }
@@ -829,6 +832,9 @@ int symmicp_step(symmicp_ctx *c, symmicp_iter_result *out)
 {
     if (!c) return SYMMICP_ERR_ARG;
     if (!c->begun) return fail(c, SYMMICP_ERR_STATE, "symmicp_step before symmicp_begin");
+    if (c->external_exchange && !c->sums_exchanged)
+        return fail(c, SYMMICP_ERR_STATE, "external exchange: symmicp_set_sums(total over ranks) must follow every pass");
+    c->sums_exchanged = false;
     HIP_TRY(c, hipSetDevice(c->device));
     float pbar[3], qbar[3], a[3], t[3], rc = 0.f, Xi[16];
     int st = (c->cfg.mode == SYMMICP_MODE_QUIRKS) ? solve_quirks(c->last, pbar, qbar, a, t, &rc, Xi)
@@ -852,6 +858,7 @@ int symmicp_align(symmicp_ctx *c, const float *guess16, symmicp_result *out)
 {
     if (!c || !out) return SYMMICP_ERR_ARG;
     std::memset(out, 0, sizeof(*out));
+    if (c->external_exchange) { out->status = SYMMICP_ERR_STATE; return fail(c, SYMMICP_ERR_STATE, "symmicp_align is not available with external exchange: drive begin/set_sums/step"); }
     const double t0 = now_s();
     symmicp_iter_result it;
     int st = symmicp_begin(c, guess16, &it);
@@ -1045,7 +1052,12 @@ int symmicp_comm_init_rank(symmicp_ctx *c, int nranks, int rank, const void *uid
     if (c->src0_block) return fail(c, SYMMICP_ERR_STATE, "attach the communicator before symmicp_set_source");
     // a 1-rank communicator is legal RCCL; it is only built on request (exercises the RCCL path on one GPU)
     if (nranks == 1 && !std::getenv("SYMMICP_FORCE_COMM")) { c->nranks = 1; c->rank = 0; return SYMMICP_OK; }
-    if (!uid) return fail(c, SYMMICP_ERR_ARG, "null unique id");
+    if (!uid) {
+        // external exchange: shard like a rank of `nranks`, publish local records, the application sums them (symmicp_set_sums)
+        if (nranks == 1) return fail(c, SYMMICP_ERR_ARG, "null unique id");
+        c->nranks = nranks; c->rank = rank; c->external_exchange = true;
+        return SYMMICP_OK;
+    }
     if (!g_rccl.load()) return fail(c, SYMMICP_ERR_COMM, g_rccl.err);
     HIP_TRY(c, hipSetDevice(c->device));
     rcclUniqueId id;
@@ -1054,6 +1066,17 @@ int symmicp_comm_init_rank(symmicp_ctx *c, int nranks, int rank, const void *uid
     if (r != 0) return fail(c, SYMMICP_ERR_COMM, std::string("ncclCommInitRank: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?"));
     c->nranks = nranks;
     c->rank = rank;
+    c->external_exchange = false;
+    return SYMMICP_OK;
+}
+
+int symmicp_set_sums(symmicp_ctx *c, const symmicp_sums *total)
+{
+    if (!c || !total) return SYMMICP_ERR_ARG;
+    if (!c->external_exchange) return fail(c, SYMMICP_ERR_STATE, "symmicp_set_sums needs external exchange (comm_init_rank with a null id)");
+    if (!c->begun) return fail(c, SYMMICP_ERR_STATE, "no pass has run yet");
+    c->last = *total;
+    c->sums_exchanged = true;
     return SYMMICP_OK;
 }
 

@@ -177,6 +177,12 @@ int symmicp_comm_get_unique_id(void *out128);
  * pure host arithmetic, the same partition symmicp_set_source applies. */
 int symmicp_shard_range(size_t n, int nranks, int rank, size_t *begin, size_t *count);
 int symmicp_comm_init_rank(symmicp_ctx *ctx, int nranks, int rank, const void *unique_id128);
+/* External exchange: with unique_id128 == NULL and nranks > 1 the context is sharded as above but owns no
+ * communicator; every pass then ends with THIS RANK's record (symmicp_iter_result.sums).  The application sums the
+ * records over the ranks however it likes (MPI, gloo, shared memory, ...) and hands the total back before the next
+ * step; all ranks must pass the same 40 doubles so that their solves agree.  (symmicp_align is not available in this
+ * mode: it would solve from the local record.) */
+int symmicp_set_sums(symmicp_ctx *ctx, const symmicp_sums *total_over_ranks);
 
 /* ---- measurement helpers ------------------------------------------------ */
 typedef struct {

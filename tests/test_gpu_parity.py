@@ -489,6 +489,62 @@ def test_rccl_path_single_rank_communicator(sym, cat, monkeypatch):
     assert r0["diff_final"] == r1["diff_final"]
 
 
+@pytest.mark.parametrize("world", [2, 5])
+def test_sharded_ranks_with_external_exchange(sym, oracle, world):
+    """The sharded engine itself, every rank of it, on this one GPU: `world` contexts in external-exchange mode (each
+    keeps its contiguous share of the Morton-sorted source, the target is replicated), the test playing the all-reduce.
+    The records must add up to the unsharded record, the shards' pairs must tile the unsharded pairs, every rank must
+    compute the same 4x4, and that 4x4 must follow the unsharded run."""
+    from symmicp import synth
+    d = synth.c4_surface(40000)
+    n = d["src"].shape[0]
+    kw = dict(mode=sym.MODE_PAPER, corr=sym.CORR_TREE, max_iters=5, fixed_iters=1)
+    with sym.Engine(**kw) as ref:
+        ref.set_target(d["tgt"], d["tgt_n"])
+        ref.set_source(d["src"], d["src_n"])
+        it_ref = ref.begin()
+        idx_ref, d2_ref = ref.correspondences()
+        T_ref = []
+        for _ in range(5):
+            ref.step()
+            T_ref.append(ref.transform())
+    engs = [sym.Engine(**kw) for _ in range(world)]
+    try:
+        for r, e in enumerate(engs):
+            e.comm_init_rank(world, r, None)
+            e.set_target(d["tgt"], d["tgt_n"])
+            e.set_source(d["src"], d["src_n"])
+        assert sum(e.local_count() for e in engs) == n
+        assert [e.local_offset() for e in engs] == list(np.cumsum([0] + [e.local_count() for e in engs[:-1]]))
+        its = [e.begin() for e in engs]
+        total = np.sum([np.asarray(it["sums"], np.float64) for it in its], axis=0)
+        _sums_close(total, np.asarray(it_ref["sums"], np.float64), 1e-11)
+        # every source row belongs to exactly one rank, with the pair the unsharded run found
+        idx = np.full(n, -1, np.int32)
+        d2 = np.zeros(n, np.float32)
+        owned = np.zeros(n, np.int32)
+        for e in engs:
+            i_r, d_r = e.correspondences()
+            m = i_r >= 0
+            owned += m
+            idx[m] = i_r[m]; d2[m] = d_r[m]
+        assert np.all(owned == 1)
+        assert np.array_equal(idx, idx_ref) and np.array_equal(d2, d2_ref)
+        with pytest.raises(sym.SymmIcpError):
+            engs[0].step()                       # the exchanged record is mandatory
+        for k in range(5):
+            for e in engs:
+                e.set_sums(total)
+            its = [e.step() for e in engs]
+            total = np.sum([np.asarray(it["sums"], np.float64) for it in its], axis=0)
+            Ts = [e.transform() for e in engs]
+            assert all(np.array_equal(Ts[0], T) for T in Ts[1:])
+            assert np.abs(Ts[0] - T_ref[k]).max() < 1e-6
+    finally:
+        for e in engs:
+            e.close()
+
+
 def test_pair_certificates_stay_exact_under_small_and_large_moves(sym, oracle):
     """Pair certificates (k_search_cells): after a search a pair is re-used while the query has provably not
     moved far enough to change its nearest neighbour.  Drive the engine with a sequence of tiny and not-so-tiny
