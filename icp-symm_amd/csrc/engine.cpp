@@ -778,8 +778,8 @@ static int run_pass(symmicp_ctx *c, const float Xapply[16], bool from_cur, bool 
         unsigned long long h[8];
         hipMemcpy(h, c->ix.dbg, sizeof(h), hipMemcpyDeviceToHost);
         hipMemset(c->ix.dbg, 0, sizeof(h));
-        std::fprintf(stderr, "[symmicp dbg] pass %lld: cells: certified=%llu scans=%llu probes=%llu to-walk=%llu items=%llu points=%llu | walk visits=%llu wave-max*64=%llu\n",
-                     (long long)c->st.passes, h[1], h[2], h[6], h[7], h[0], h[3], h[4], h[5]);
+        std::fprintf(stderr, "[symmicp dbg] pass %lld: cells: certified=%llu scans=%llu probes=%llu to-walk=%llu items=%llu points=%llu | walk list=%lld visits=%llu wave-max*64=%llu\n",
+                     (long long)c->st.passes, h[1], h[2], h[6], h[7], h[0], h[3], list_len, h[4], h[5]);
     }
     std::memcpy(c->last.s, c->h_sums, sizeof(double) * kNSum);
     if (c->cfg.corr == SYMMICP_CORR_TREE) c->last.s[kNSum - 1] = 0.0;      // that slot carried the list length, not a sum
