@@ -50,11 +50,20 @@ def run(budget_s=None, max_cases=None, seed=0, verbose=True):
         cases += 1
         with sym.Engine(mode=mode, corr=sym.CORR_TREE, apply=apply_mode, max_iters=6, fixed_iters=1) as e:
             e.set_target(tgt, tn); e.set_source(src, sn)
-            e.begin()
+            last = e.begin()
             for it in range(6):
                 idx, d2 = e.correspondences()
                 if apply_mode == sym.APPLY_INCREMENTAL:
-                    p, _ = e.source(); ri, rd = oracle.nn_grid(p, tgt)
+                    p, pn = e.source(); ri, rd = oracle.nn_grid(p, tgt)
+                    # the pass's 40-double record against a host recomputation from the returned pairs
+                    S = oracle.reduce40(p, pn, tgt, tn, idx=idx, pivot=None if mode == sym.MODE_QUIRKS else e.pivot(),
+                                        p2p=(mode == sym.MODE_P2P))
+                    g = np.asarray(last["sums"], np.float64)
+                    if np.abs(g - S).max() > 1e-9 * max(1.0, np.abs(S).max()):
+                        failures.append(dict(case, it=it, sums_err=float(np.abs(g - S).max() / max(1.0, np.abs(S).max()))))
+                        if verbose:
+                            print("SUMS", failures[-1], flush=True)
+                        break
                 else:
                     ri, rd = oracle.nn_grid(src, tgt, X=e.transform())
                 if not (np.array_equal(idx, ri) and np.array_equal(d2, rd)):
@@ -62,7 +71,8 @@ def run(budget_s=None, max_cases=None, seed=0, verbose=True):
                     if verbose:
                         print("MISMATCH", failures[-1], flush=True)
                     break
-                if e.step(check=False)["status"] != 0:
+                last = e.step(check=False)
+                if last["status"] != 0:
                     break                               # degenerate system: legitimately flagged
     return cases, failures
 
