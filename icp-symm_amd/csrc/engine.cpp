@@ -287,26 +287,46 @@ int symmicp_set_config(symmicp_ctx *c, const symmicp_config *cfg)
     return SYMMICP_OK;
 }
 
-// host strided -> planar staging -> device block of 6 arrays
+// host strided cloud -> device block of 6 planar arrays.  The usual layouts never touch a host staging loop: records with
+// contiguous x y z (packed AoS, PointXYZ, PointNormal) are copied as they are and split into columns on the device;
+// column-major matrices (Eigen) are copied column by column.  Anything else goes through a host transpose.
 static int upload_planar(symmicp_ctx *c, const float *xyz, size_t xr, size_t xc, const float *nrm, size_t nr, size_t nc,
                          size_t n, float **block_out, double centroid[3])
 {
-    std::vector<float> stage(6 * n);
-    double s[3] = {0, 0, 0};
-    for (size_t i = 0; i < n; i++)
-        for (int k = 0; k < 3; k++) {
-            float v = xyz[i * xr + k * xc];
-            stage[(size_t)k * n + i] = v;
-            s[k] += (double)v;
-            stage[(size_t)(3 + k) * n + i] = nrm[i * nr + k * nc];
+    if (centroid) {
+        // fp64, in row order (the oracle's order: the pivot has to come out bit-identical)
+        double s[3] = {0, 0, 0};
+        for (size_t i = 0; i < n; i++)
+            for (int k = 0; k < 3; k++) s[k] += (double)xyz[i * xr + k * xc];
+        for (int k = 0; k < 3; k++) centroid[k] = s[k] / (double)n;
+    }
+    DevBuf<float> block;
+    HIP_TRY(c, block.alloc(6 * n));
+    float *col[6];
+    for (int k = 0; k < 6; k++) col[k] = block.p + (size_t)k * n;
+    struct Part { const float *base; size_t rs, cs; int first_col; } parts[2] = {{xyz, xr, xc, 0}, {nrm, nr, nc, 3}};
+    for (const Part &p : parts) {
+        if (p.cs == 1 && p.rs >= 3) {
+            const size_t fl = (n - 1) * p.rs + 3;                  // floats from the first x to the last z
+            DevBuf<float> raw;
+            HIP_TRY(c, raw.alloc(fl));
+            HIP_TRY(c, hipMemcpyAsync(raw.p, p.base, sizeof(float) * fl, hipMemcpyHostToDevice, c->stream));
+            launch_deinterleave3(raw.p, p.rs, 0, (uint32_t)n, col[p.first_col], col[p.first_col + 1], col[p.first_col + 2], c->stream);
+            HIP_TRY(c, hipStreamSynchronize(c->stream));           // raw is freed on scope exit
+        } else if (p.rs == 1 && p.cs >= n) {
+            for (int k = 0; k < 3; k++)
+                HIP_TRY(c, hipMemcpyAsync(col[p.first_col + k], p.base + (size_t)k * p.cs, sizeof(float) * n, hipMemcpyHostToDevice, c->stream));
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+        } else {
+            std::vector<float> stage(3 * n);
+            for (size_t i = 0; i < n; i++)
+                for (int k = 0; k < 3; k++) stage[(size_t)k * n + i] = p.base[i * p.rs + k * p.cs];
+            HIP_TRY(c, hipMemcpyAsync(col[p.first_col], stage.data(), sizeof(float) * 3 * n, hipMemcpyHostToDevice, c->stream));
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
         }
-    if (centroid) for (int k = 0; k < 3; k++) centroid[k] = s[k] / (double)n;
-    float *block = nullptr;
-    HIP_TRY(c, hipMalloc((void **)&block, sizeof(float) * 6 * n));
-    hipError_t e = hipMemcpyAsync(block, stage.data(), sizeof(float) * 6 * n, hipMemcpyHostToDevice, c->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    if (e != hipSuccess) { hipFree(block); c->err = std::string("upload: ") + hipGetErrorString(e); return SYMMICP_ERR_HIP; }
-    *block_out = block;
+    }
+    HIP_TRY(c, hipGetLastError());
+    *block_out = block.release();
     return SYMMICP_OK;
 }
 

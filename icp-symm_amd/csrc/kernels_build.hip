@@ -218,6 +218,21 @@ __global__ __launch_bounds__(256) void k_gather_f4(const float *__restrict__ x, 
     tn[2 * (size_t)i + 1] = make_float4(nx[j], ny[j], nz[j], 0.0f);
 }
 
+// host rows (x y z at float offset `offset` of every `row_stride`-float record) -> three planar columns
+__global__ __launch_bounds__(256) void k_deinterleave3(const float *__restrict__ raw, size_t row_stride, size_t offset, uint32_t n,
+                                                       float *__restrict__ x, float *__restrict__ y, float *__restrict__ z)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float *r = raw + (size_t)i * row_stride + offset;
+    x[i] = r[0]; y[i] = r[1]; z[i] = r[2];
+}
+
+void launch_deinterleave3(const float *raw, size_t row_stride, size_t offset, uint32_t n, float *x, float *y, float *z, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_deinterleave3, dim3((n + 255) / 256), dim3(256), 0, s, raw, row_stride, offset, n, x, y, z);
+}
+
 __global__ __launch_bounds__(256) void k_gather_soa(CloudSoA src, const uint32_t *__restrict__ order, uint32_t n, CloudSoA dst)
 {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
