@@ -69,7 +69,16 @@ double now_s()
 }
 }  // namespace
 
+// Scratch arena of a context: the builds need dozens of temporaries, and every hipFree costs ~100 us (it synchronises the
+// device) -- half of a set_target + set_source at 1M points.  Temporaries are bump-allocated from one block that is
+// rewound at the start of each public call and only ever grows; persistent results are hipMalloc'ed as before.
+struct Arena {
+    char *base = nullptr;
+    size_t cap = 0, off = 0;
+};
+
 struct symmicp_ctx {
+    Arena arena;
     symmicp_config cfg{};
     int device = 0;
     hipStream_t stream = nullptr;
@@ -124,17 +133,37 @@ struct symmicp_ctx {
     symmicp_stats st{};
 };
 
-// temporary device allocation, freed on every exit path (release() hands the pointer over to the context)
+// device buffer freed on every exit path.  alloc(): its own hipMalloc (release() hands the pointer to the context);
+// alloc_temp(): from the context's arena when it fits (nothing to free), else its own hipMalloc.
 template <typename T>
 struct DevBuf {
     T *p = nullptr;
+    bool owned = true;
     DevBuf() = default;
     DevBuf(const DevBuf &) = delete;
     DevBuf &operator=(const DevBuf &) = delete;
-    ~DevBuf() { if (p) hipFree(p); }
-    hipError_t alloc(size_t count) { return hipMalloc((void **)&p, sizeof(T) * (count ? count : 1)); }
-    T *release() { T *q = p; p = nullptr; return q; }
+    ~DevBuf() { if (p && owned) hipFree(p); }
+    hipError_t alloc(size_t count) { owned = true; return hipMalloc((void **)&p, sizeof(T) * (count ? count : 1)); }
+    hipError_t alloc_temp(Arena &a, size_t count)
+    {
+        const size_t bytes = ((sizeof(T) * (count ? count : 1)) + 255) & ~(size_t)255;
+        if (a.base && a.off + bytes <= a.cap) { p = reinterpret_cast<T *>(a.base + a.off); a.off += bytes; owned = false; return hipSuccess; }
+        return alloc(count);
+    }
+    T *release() { T *q = p; p = nullptr; return q; }           // (owned buffers only)
 };
+
+// rewind the arena and make sure it holds `want` bytes (contents are dead: called at the start of a public call)
+static void arena_begin(Arena &a, size_t want)
+{
+    a.off = 0;
+    if (a.cap >= want) return;
+    if (a.base) hipFree(a.base);
+    a.base = nullptr; a.cap = 0;
+    const size_t cap = want + want / 4;
+    if (hipMalloc((void **)&a.base, cap) == hipSuccess) a.cap = cap;      // on failure every alloc_temp falls back to hipMalloc
+    else (void)hipGetLastError();
+}
 
 #define HIP_TRY(ctx, call)                                                                                  \
     do {                                                                                                    \
@@ -264,7 +293,7 @@ void symmicp_destroy(symmicp_ctx *c)
     if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
     free_target(c);
     free_source(c);
-    hipFree(c->partials); hipFree(c->d_sums); hipFree(c->ticket);
+    hipFree(c->partials); hipFree(c->d_sums); hipFree(c->ticket); hipFree(c->arena.base);
     if (c->h_sums) hipHostFree(c->h_sums);
     for (hipEvent_t e : c->ev) if (e) hipEventDestroy(e);
     if (c->stream) hipStreamDestroy(c->stream);
@@ -291,7 +320,7 @@ int symmicp_set_config(symmicp_ctx *c, const symmicp_config *cfg)
 // contiguous x y z (packed AoS, PointXYZ, PointNormal) are copied as they are and split into columns on the device;
 // column-major matrices (Eigen) are copied column by column.  Anything else goes through a host transpose.
 static int upload_planar(symmicp_ctx *c, const float *xyz, size_t xr, size_t xc, const float *nrm, size_t nr, size_t nc,
-                         size_t n, float **block_out, double centroid[3])
+                         size_t n, DevBuf<float> &block, bool temp, double centroid[3])
 {
     if (centroid) {
         // fp64, in row order (the oracle's order: the pivot has to come out bit-identical)
@@ -300,8 +329,7 @@ static int upload_planar(symmicp_ctx *c, const float *xyz, size_t xr, size_t xc,
             for (int k = 0; k < 3; k++) s[k] += (double)xyz[i * xr + k * xc];
         for (int k = 0; k < 3; k++) centroid[k] = s[k] / (double)n;
     }
-    DevBuf<float> block;
-    HIP_TRY(c, block.alloc(6 * n));
+    HIP_TRY(c, temp ? block.alloc_temp(c->arena, 6 * n) : block.alloc(6 * n));
     float *col[6];
     for (int k = 0; k < 6; k++) col[k] = block.p + (size_t)k * n;
     struct Part { const float *base; size_t rs, cs; int first_col; } parts[2] = {{xyz, xr, xc, 0}, {nrm, nr, nc, 3}};
@@ -309,7 +337,7 @@ static int upload_planar(symmicp_ctx *c, const float *xyz, size_t xr, size_t xc,
         if (p.cs == 1 && p.rs >= 3) {
             const size_t fl = (n - 1) * p.rs + 3;                  // floats from the first x to the last z
             DevBuf<float> raw;
-            HIP_TRY(c, raw.alloc(fl));
+            HIP_TRY(c, raw.alloc_temp(c->arena, fl));
             HIP_TRY(c, hipMemcpyAsync(raw.p, p.base, sizeof(float) * fl, hipMemcpyHostToDevice, c->stream));
             launch_deinterleave3(raw.p, p.rs, 0, (uint32_t)n, col[p.first_col], col[p.first_col + 1], col[p.first_col + 2], c->stream);
             HIP_TRY(c, hipStreamSynchronize(c->stream));           // raw is freed on scope exit
@@ -326,7 +354,6 @@ static int upload_planar(symmicp_ctx *c, const float *xyz, size_t xr, size_t xc,
         }
     }
     HIP_TRY(c, hipGetLastError());
-    *block_out = block.release();
     return SYMMICP_OK;
 }
 
@@ -339,17 +366,18 @@ static float ord2f(uint32_t o)
 }
 
 // Morton order of a planar cloud: fills order[n] (sorted position -> row) and, optionally, keeps the sorted keys.
-static int morton_order(symmicp_ctx *c, const CloudSoA &cl, uint32_t n, uint32_t **order_out, uint32_t **keys_out,
+static int morton_order(symmicp_ctx *c, const CloudSoA &cl, uint32_t n, DevBuf<uint32_t> &vals, DevBuf<uint32_t> *keys_out,
                         float origin[3], float *h0_out)
 {
-    DevBuf<uint32_t> bbox, keys, vals, kt, vt, ws;
+    DevBuf<uint32_t> bbox, keys_local, kt, vt, ws;
+    DevBuf<uint32_t> &keys = keys_out ? *keys_out : keys_local;
     const size_t wse = radix_sort_ws_elems(n);
-    HIP_TRY(c, bbox.alloc(6));
-    HIP_TRY(c, keys.alloc(n));
-    HIP_TRY(c, vals.alloc(n));
-    HIP_TRY(c, kt.alloc(n));
-    HIP_TRY(c, vt.alloc(n));
-    HIP_TRY(c, ws.alloc(wse));
+    HIP_TRY(c, bbox.alloc_temp(c->arena, 6));
+    HIP_TRY(c, keys.alloc_temp(c->arena, n));
+    HIP_TRY(c, vals.alloc_temp(c->arena, n));
+    HIP_TRY(c, kt.alloc_temp(c->arena, n));
+    HIP_TRY(c, vt.alloc_temp(c->arena, n));
+    HIP_TRY(c, ws.alloc_temp(c->arena, wse));
     launch_bbox(cl.x, cl.y, cl.z, n, bbox.p, c->stream);
     uint32_t hb[6];
     HIP_TRY(c, hipMemcpyAsync(hb, bbox.p, sizeof(hb), hipMemcpyDeviceToHost, c->stream));
@@ -367,8 +395,6 @@ static int morton_order(symmicp_ctx *c, const CloudSoA &cl, uint32_t n, uint32_t
     radix_sort_pairs(keys.p, vals.p, kt.p, vt.p, n, 3 * kMortonBits, ws.p, wse, c->stream);
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     HIP_TRY(c, hipGetLastError());
-    *order_out = vals.release();
-    if (keys_out) *keys_out = keys.release();
     for (int k = 0; k < 3; k++) origin[k] = lo[k];
     *h0_out = h0;
     return SYMMICP_OK;
@@ -383,8 +409,8 @@ static int build_octree(symmicp_ctx *c, const uint32_t *keys, const float4 *tq, 
     DevBuf<uint32_t> nid;                         // [NL][n]: id of the node that starts at point i, per level
     DevBuf<uint32_t> scan_ws, first;
     DevBuf<float4> nodes;
-    HIP_TRY(c, nid.alloc((size_t)NL * n));
-    HIP_TRY(c, scan_ws.alloc((size_t)n / 2048 + 2));
+    HIP_TRY(c, nid.alloc_temp(c->arena, (size_t)NL * n));
+    HIP_TRY(c, scan_ws.alloc_temp(c->arena, (size_t)n / 2048 + 2));
     for (int l = 0; l < NL; l++) {
         launch_oct_flags(keys, n, l, nid.p + (size_t)l * n, c->stream);
         launch_exclusive_scan(nid.p + (size_t)l * n, n, scan_ws.p, c->stream);
@@ -408,7 +434,7 @@ static int build_octree(symmicp_ctx *c, const uint32_t *keys, const float4 *tq, 
     for (int l = 0; l < NL; l++)
         // child_first is a 24-bit field (node word and walk stack word): targets beyond ~16.7M distinct finest cells are refused
         if (cnt[l] > 0xFFFFFFu) return fail(c, SYMMICP_ERR_SIZE, "octree level exceeds 2^24 nodes (target cloud too large for SYMMICP_CORR_TREE)");
-    HIP_TRY(c, first.alloc(total + 1));
+    HIP_TRY(c, first.alloc_temp(c->arena, total + 1));
     HIP_TRY(c, nodes.alloc(2 * total));
     for (int l = 0; l < NL; l++)
         launch_oct_first(keys, n, l, nid.p + (size_t)l * n, first.p + ix->olevel_off[l], c->stream);
@@ -433,7 +459,7 @@ static int build_index(symmicp_ctx *c, const CloudSoA &cl, uint32_t n, bool want
 {
     DevBuf<uint32_t> order, keys;
     float origin[3], h0;
-    int st = morton_order(c, cl, n, &order.p, &keys.p, origin, &h0);
+    int st = morton_order(c, cl, n, order, &keys, origin, &h0);
     if (st != SYMMICP_OK) return st;
     launch_gather_f4(cl.x, cl.y, cl.z, cl.nx, cl.ny, cl.nz, order.p, n, tq, tn, c->stream);
     TargetIndex ix{};
@@ -441,7 +467,7 @@ static int build_index(symmicp_ctx *c, const CloudSoA &cl, uint32_t n, bool want
     int glevel = 0;
     if (want_grid) {
         DevBuf<uint32_t> hist;
-        HIP_TRY(c, hist.alloc(16));
+        HIP_TRY(c, hist.alloc_temp(c->arena, 16));
         launch_level_hist(keys.p, n, hist.p, c->stream);
         uint32_t hh[16];
         HIP_TRY(c, hipMemcpyAsync(hh, hist.p, sizeof(hh), hipMemcpyDeviceToHost, c->stream));
@@ -468,8 +494,8 @@ static int build_index(symmicp_ctx *c, const CloudSoA &cl, uint32_t n, bool want
         const size_t ntop = (size_t)1 << (3 * ltop);
         // block numbers of the occupied super-cells: exclusive scan of their start flags
         DevBuf<uint32_t> nid_top, scan_ws;
-        HIP_TRY(c, nid_top.alloc(n));
-        HIP_TRY(c, scan_ws.alloc((size_t)n / 2048 + 2));
+        HIP_TRY(c, nid_top.alloc_temp(c->arena, n));
+        HIP_TRY(c, scan_ws.alloc_temp(c->arena, (size_t)n / 2048 + 2));
         launch_oct_flags(keys.p, n, ltop, nid_top.p, c->stream);
         launch_exclusive_scan(nid_top.p, n, scan_ws.p, c->stream);
         uint32_t last_excl = 0, kl[2] = {0, 0};
@@ -536,9 +562,13 @@ int symmicp_set_target(symmicp_ctx *c, const float *xyz, size_t xr, size_t xc, c
     const double t0 = now_s();
     free_target(c);
     c->begun = false;
+    // temporaries of the upload and of the index build: ~80 B per point (11 octree-level id arrays, sort buffers, raw rows)
+    arena_begin(c->arena, n * (96 + 4 * (xr + nr)) + ((size_t)1 << 20));
     double cen[3];
-    int st = upload_planar(c, xyz, xr, xc, nrm, nr, nc, n, &c->tgt_block, cen);
+    DevBuf<float> tblock;
+    int st = upload_planar(c, xyz, xr, xc, nrm, nr, nc, n, tblock, /*temp=*/false, cen);
     if (st != SYMMICP_OK) return st;
+    c->tgt_block = tblock.release();
     soa_from_block(c->tgt_block, n, c->tgt);
     c->n_t = (uint32_t)n;
     for (int k = 0; k < 3; k++) c->pivot[k] = (float)cen[k];
@@ -576,8 +606,9 @@ int symmicp_set_source(symmicp_ctx *c, const float *xyz, size_t xr, size_t xc, c
     const double t0 = now_s();
     free_source(c);
     c->begun = false;
+    arena_begin(c->arena, n * (48 + 4 * (xr + nr)) + ((size_t)1 << 20));
     DevBuf<float> full;
-    int st = upload_planar(c, xyz, xr, xc, nrm, nr, nc, n, &full.p, nullptr);
+    int st = upload_planar(c, xyz, xr, xc, nrm, nr, nc, n, full, /*temp=*/true, nullptr);
     if (st != SYMMICP_OK) return st;
     CloudSoA fs;
     soa_from_block(full.p, n, fs);
@@ -596,7 +627,7 @@ int symmicp_set_source(symmicp_ctx *c, const float *xyz, size_t xr, size_t xc, c
     if (sorted) {
         DevBuf<uint32_t> order;
         float origin[3], h0;
-        st = morton_order(c, fs, (uint32_t)n, &order.p, nullptr, origin, &h0);
+        st = morton_order(c, fs, (uint32_t)n, order, nullptr, origin, &h0);
         if (st != SYMMICP_OK) return st;
         HIP_TRY(c, hipMalloc((void **)&c->src_order, sizeof(uint32_t) * nl));
         if (c->n_loc) {
@@ -611,7 +642,6 @@ int symmicp_set_source(symmicp_ctx *c, const float *xyz, size_t xr, size_t xc, c
             HIP_TRY(c, hipMemcpyAsync(to[k], from[k] + b0, sizeof(float) * c->n_loc, hipMemcpyDeviceToDevice, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
     }
-    hipFree(full.release());
     HIP_TRY(c, hipMalloc((void **)&c->pos, sizeof(int32_t) * nl));
     HIP_TRY(c, hipMalloc((void **)&c->d2, sizeof(float) * nl));
     if (c->cfg.corr == SYMMICP_CORR_BRUTE) HIP_TRY(c, hipMalloc((void **)&c->best64, sizeof(unsigned long long) * nl));
@@ -947,8 +977,9 @@ int symmicp_get_correspondences(symmicp_ctx *c, int32_t *idx, float *d2, size_t 
     HIP_TRY(c, hipSetDevice(c->device));
     DevBuf<int32_t> d_idx;
     DevBuf<float> d_d2;
-    HIP_TRY(c, d_idx.alloc(need));
-    HIP_TRY(c, d_d2.alloc(need));
+    arena_begin(c->arena, need * 8 + 4096);
+    HIP_TRY(c, d_idx.alloc_temp(c->arena, need));
+    HIP_TRY(c, d_d2.alloc_temp(c->arena, need));
     HIP_TRY(c, hipMemsetAsync(d_idx.p, 0xFF, sizeof(int32_t) * need, c->stream));
     HIP_TRY(c, hipMemsetAsync(d_d2.p, 0, sizeof(float) * need, c->stream));
     const int mode = c->cfg.corr == SYMMICP_CORR_IDENTITY ? 0 : (c->cfg.corr == SYMMICP_CORR_BRUTE ? 1 : 2);
@@ -980,8 +1011,9 @@ int symmicp_get_source(symmicp_ctx *c, float *xyz, float *nrm, size_t cap)
     if (cap < need) return fail(c, SYMMICP_ERR_SIZE, "output too small");
     HIP_TRY(c, hipSetDevice(c->device));
     DevBuf<float> dx, dn;
-    HIP_TRY(c, dx.alloc(3 * need));
-    HIP_TRY(c, dn.alloc(3 * need));
+    arena_begin(c->arena, need * 24 + 4096);
+    HIP_TRY(c, dx.alloc_temp(c->arena, 3 * need));
+    HIP_TRY(c, dn.alloc_temp(c->arena, 3 * need));
     HIP_TRY(c, hipMemsetAsync(dx.p, 0, sizeof(float) * 3 * need, c->stream));
     HIP_TRY(c, hipMemsetAsync(dn.p, 0, sizeof(float) * 3 * need, c->stream));
     launch_unpermute(c->cur, c->src_order, c->n_loc, dx.p, dn.p, c->stream);
@@ -1024,8 +1056,13 @@ int symmicp_estimate_normals(int device, const float *xyz, size_t row_stride, si
         symmicp_destroy(c);
     };
     // the cloud has no normals yet: stage xyz twice (the normal slots are ignored)
-    st = upload_planar(c, xyz, row_stride, col_stride, xyz, row_stride, col_stride, n, &block, nullptr);
-    if (st != SYMMICP_OK) { cleanup(); return st; }
+    arena_begin(c->arena, n * (96 + 8 * row_stride) + ((size_t)1 << 20));
+    {
+        DevBuf<float> b;
+        st = upload_planar(c, xyz, row_stride, col_stride, xyz, row_stride, col_stride, n, b, /*temp=*/false, nullptr);
+        if (st != SYMMICP_OK) { cleanup(); return st; }
+        block = b.release();
+    }
     CloudSoA cl;
     soa_from_block(block, n, cl);
     TargetIndex ix{};
