@@ -103,6 +103,8 @@ struct symmicp_ctx {
     float pivot[3] = {0, 0, 0};
     // source share
     uint32_t n_s_total = 0, n_loc = 0, src_off = 0;
+    char *src_all = nullptr;         // one allocation behind all per-source arrays below (reused by the next set_source)
+    size_t src_all_cap = 0;
     float *src0_block = nullptr, *cur_block = nullptr;
     CloudSoA src0{}, cur{};
     uint32_t *src_order = nullptr;   // share position -> row in the caller's cloud (null = identity)
@@ -275,12 +277,19 @@ static void free_target(symmicp_ctx *c)
     c->have_index = false; c->n_t = 0;
 }
 
-static void free_source(symmicp_ctx *c)
+static void forget_source(symmicp_ctx *c)
 {
-    hipFree(c->src0_block); hipFree(c->cur_block); hipFree(c->src_order); hipFree(c->pos); hipFree(c->d2); hipFree(c->cert); hipFree(c->best64); hipFree(c->worklist); hipFree(c->wl_count);
+    // (the arrays live in one block, c->src_all, which is kept for the next source of the same or a smaller size)
     c->worklist = c->wl_count = nullptr; c->cert = nullptr;
     c->src0_block = c->cur_block = nullptr; c->src_order = nullptr; c->pos = nullptr; c->d2 = nullptr; c->best64 = nullptr;
     c->n_loc = c->n_s_total = c->src_off = 0;
+}
+
+static void free_source(symmicp_ctx *c)
+{
+    forget_source(c);
+    hipFree(c->src_all);
+    c->src_all = nullptr; c->src_all_cap = 0;
 }
 
 void symmicp_destroy(symmicp_ctx *c)
@@ -604,7 +613,7 @@ int symmicp_set_source(symmicp_ctx *c, const float *xyz, size_t xr, size_t xc, c
     if (n == 0 || n > 0x7fffffffull) return fail(c, SYMMICP_ERR_SIZE, "source size out of range");
     HIP_TRY(c, hipSetDevice(c->device));
     const double t0 = now_s();
-    free_source(c);
+    forget_source(c);
     c->begun = false;
     arena_begin(c->arena, n * (48 + 4 * (xr + nr)) + ((size_t)1 << 20));
     DevBuf<float> full;
@@ -612,50 +621,66 @@ int symmicp_set_source(symmicp_ctx *c, const float *xyz, size_t xr, size_t xc, c
     if (st != SYMMICP_OK) return st;
     CloudSoA fs;
     soa_from_block(full.p, n, fs);
-    c->n_s_total = (uint32_t)n;
     // contiguous share of the (sorted) source for this rank
     size_t b0 = 0, bc = 0;
     symmicp_shard_range(n, c->nranks, c->rank, &b0, &bc);
+    const uint32_t nl = bc > 0 ? (uint32_t)bc : 1;
+    const bool sorted = c->cfg.corr != SYMMICP_CORR_IDENTITY && c->cfg.sort_source;
+    const bool tree = c->cfg.corr == SYMMICP_CORR_TREE, brute = c->cfg.corr == SYMMICP_CORR_BRUTE;
+    // every per-source array in ONE allocation (a hipFree costs ~100 us, and a tracker calls this once per frame)
+    const uint32_t cap = shard_capacity(nl);
+    const size_t per_list = (size_t)kShards * cap, ncount = (size_t)kShards * kShardStride;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
+    const size_t o_src0 = take(sizeof(float) * 6 * nl), o_cur = take(sizeof(float) * 6 * nl);
+    const size_t o_order = sorted ? take(sizeof(uint32_t) * nl) : 0;
+    const size_t o_pos = take(sizeof(int32_t) * nl), o_d2 = take(sizeof(float) * nl);
+    const size_t o_best = brute ? take(sizeof(unsigned long long) * nl) : 0;
+    const size_t o_cert = tree ? take(sizeof(float) * 4 * nl) : 0;
+    const size_t o_wl = tree ? take(sizeof(uint32_t) * per_list) : 0, o_cnt = tree ? take(sizeof(uint32_t) * ncount) : 0;
+    if (off > c->src_all_cap) {
+        hipFree(c->src_all);
+        c->src_all = nullptr; c->src_all_cap = 0;
+        HIP_TRY(c, hipMalloc((void **)&c->src_all, off));
+        c->src_all_cap = off;
+    }
+    c->n_s_total = (uint32_t)n;
     c->src_off = (uint32_t)b0;
     c->n_loc = (uint32_t)bc;
-    const uint32_t nl = c->n_loc > 0 ? c->n_loc : 1;
-    HIP_TRY(c, hipMalloc((void **)&c->src0_block, sizeof(float) * 6 * nl));
-    HIP_TRY(c, hipMalloc((void **)&c->cur_block, sizeof(float) * 6 * nl));
+    c->src0_block = reinterpret_cast<float *>(c->src_all + o_src0);
+    c->cur_block = reinterpret_cast<float *>(c->src_all + o_cur);
     soa_from_block(c->src0_block, nl, c->src0);
     soa_from_block(c->cur_block, nl, c->cur);
-    const bool sorted = c->cfg.corr != SYMMICP_CORR_IDENTITY && c->cfg.sort_source;
+    c->pos = reinterpret_cast<int32_t *>(c->src_all + o_pos);
+    c->d2 = reinterpret_cast<float *>(c->src_all + o_d2);
+    if (brute) c->best64 = reinterpret_cast<unsigned long long *>(c->src_all + o_best);
     if (sorted) {
         DevBuf<uint32_t> order;
         float origin[3], h0;
         st = morton_order(c, fs, (uint32_t)n, order, nullptr, origin, &h0);
-        if (st != SYMMICP_OK) return st;
-        HIP_TRY(c, hipMalloc((void **)&c->src_order, sizeof(uint32_t) * nl));
+        if (st != SYMMICP_OK) { forget_source(c); return st; }
+        c->src_order = reinterpret_cast<uint32_t *>(c->src_all + o_order);
         if (c->n_loc) {
             HIP_TRY(c, hipMemcpyAsync(c->src_order, order.p + b0, sizeof(uint32_t) * c->n_loc, hipMemcpyDeviceToDevice, c->stream));
             launch_gather_soa(fs, c->src_order, c->n_loc, c->src0, c->stream);
         }
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
     } else if (c->n_loc) {
         const float *from[6] = {fs.x, fs.y, fs.z, fs.nx, fs.ny, fs.nz};
         float *to[6] = {c->src0.x, c->src0.y, c->src0.z, c->src0.nx, c->src0.ny, c->src0.nz};
         for (int k = 0; k < 6; k++)
             HIP_TRY(c, hipMemcpyAsync(to[k], from[k] + b0, sizeof(float) * c->n_loc, hipMemcpyDeviceToDevice, c->stream));
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
     }
-    HIP_TRY(c, hipMalloc((void **)&c->pos, sizeof(int32_t) * nl));
-    HIP_TRY(c, hipMalloc((void **)&c->d2, sizeof(float) * nl));
-    if (c->cfg.corr == SYMMICP_CORR_BRUTE) HIP_TRY(c, hipMalloc((void **)&c->best64, sizeof(unsigned long long) * nl));
-    if (c->cfg.corr == SYMMICP_CORR_TREE) {
-        HIP_TRY(c, hipMalloc((void **)&c->cert, sizeof(float) * 4 * nl));
-        HIP_TRY(c, hipMemset(c->cert, 0, sizeof(float) * 4 * nl));
-        const uint32_t cap = shard_capacity(nl);
-        const size_t per_list = (size_t)kShards * cap, ncount = (size_t)kShards * kShardStride;
-        HIP_TRY(c, hipMalloc((void **)&c->worklist, sizeof(uint32_t) * per_list));
-        HIP_TRY(c, hipMalloc((void **)&c->wl_count, sizeof(uint32_t) * ncount));
-        HIP_TRY(c, hipMemset(c->wl_count, 0, sizeof(uint32_t) * ncount));
+    if (tree) {
+        c->cert = reinterpret_cast<float *>(c->src_all + o_cert);
+        c->worklist = reinterpret_cast<uint32_t *>(c->src_all + o_wl);
+        c->wl_count = reinterpret_cast<uint32_t *>(c->src_all + o_cnt);
+        HIP_TRY(c, hipMemsetAsync(c->cert, 0, sizeof(float) * 4 * nl, c->stream));
+        HIP_TRY(c, hipMemsetAsync(c->wl_count, 0, sizeof(uint32_t) * ncount, c->stream));
         c->wl.work = ShardList{c->worklist, c->wl_count, cap};
     }
+    HIP_TRY(c, hipStreamSynchronize(c->stream));       // (the arena-backed upload is read by the gather above)
     HIP_TRY(c, hipGetLastError());
+    c->last_list_len = -1;
     c->st.upload_ms += (now_s() - t0) * 1e3;
     return SYMMICP_OK;
 }
