@@ -14,6 +14,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -43,9 +44,11 @@ struct Rccl {
     fn_ncclAllReduce AllReduce = nullptr;
     fn_ncclGetErrorString GetErrorString = nullptr;
     std::string err;
+    std::mutex mu;
     bool load()
     {
-        if (handle) return true;
+        std::lock_guard<std::mutex> lock(mu);       // contexts of different host threads may attach communicators concurrently
+        if (handle && AllReduce) return true;
         // prefer an RCCL already mapped into the process (e.g. the copy torch links against)
         const char *names[] = {"librccl.so.1", "librccl.so"};
         for (const char *nm : names) { handle = dlopen(nm, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL); if (handle) break; }
@@ -176,6 +179,7 @@ static void arena_begin(Arena &a, size_t want)
         }                                                                                                   \
     } while (0)
 
+// host-side timing of the pass loop, printed by symmicp_destroy under SYMMICP_DEBUG_HOST (debugging aid: process-wide, unsynchronised)
 static double g_t_launch = 0, g_t_spin = 0, g_t_between = 0, g_t_last_done = 0;
 static long g_n_pass = 0;
 
