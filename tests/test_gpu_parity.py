@@ -5,6 +5,9 @@ Bars: nearest-neighbour rows and squared distances are BIT-EXACT (integer/index 
 expression on both sides); reduction records agree to 1e-11 relative (fp64 sums, different order);
 final 4x4 transforms agree to 1e-4 max-abs (BASELINE.json north_star tolerance).
 """
+import os
+import sys
+
 import numpy as np
 import pytest
 
@@ -552,6 +555,18 @@ def test_randomised_exactness_sweep(sym, oracle):
     import _fuzz_nn
     cases, failures = _fuzz_nn.run(max_cases=60, seed=7, verbose=False)
     assert cases == 60 and not failures, failures[:3]
+
+
+def test_forced_repair_path_in_a_subprocess(sym):
+    """SYMMICP_OPTIMISTIC=1 makes every pass skip the tree walk and repair itself afterwards if a query needed it (the
+    switch is read once per process, hence the child process): the multi-pass exactness tests must still hold."""
+    import subprocess
+    env = dict(os.environ, SYMMICP_OPTIMISTIC="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
+                        "-k", "tree_follows_previous_pairs or randomised_exactness or pair_certificates or partial_overlap or sharded_ranks"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout
 
 
 def test_pair_certificates_stay_exact_under_small_and_large_moves(sym, oracle):
