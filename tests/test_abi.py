@@ -137,3 +137,43 @@ def test_host_solve_p2p_matches_oracle(sym, oracle, cat):
     c, s = np.cos(np.pi / 4), np.sin(np.pi / 4)
     T = np.array([[c, -s, 0, 2.5], [s, c, 0, 0], [0, 0, 1, 0], [0, 0, 0, 1]])
     assert np.abs(X - T).max() < 1e-5
+
+
+def test_header_is_plain_c_and_links_from_c(sym, tmp_path):
+    """include/symmicp.h is the drop-in boundary: it must compile as C99 (no C++ in the signatures) and a C program
+    must link against libsymmicp.so and get a clean error, not a crash, without a GPU."""
+    import subprocess
+    src = tmp_path / "abi.c"
+    src.write_text(r'''
+#include <stdio.h>
+#include "symmicp.h"
+int main(void) {
+    symmicp_config cfg;
+    symmicp_ctx *ctx = NULL;
+    symmicp_sums s;
+    float X[16], pbar[3], qbar[3], a[3], t[3], rc = 0.f;
+    size_t b = 0, c = 0;
+    int k, st;
+    symmicp_config_default(&cfg);
+    if (cfg.struct_size != (int)sizeof(cfg) || cfg.max_iters != 10) return 2;
+    if (symmicp_shard_range(10, 3, 2, &b, &c) != SYMMICP_OK || b + c != 10) return 3;
+    for (k = 0; k < SYMMICP_NSUM; k++) s.s[k] = 0.0;
+    st = symmicp_solve(SYMMICP_MODE_PAPER, &s, NULL, pbar, qbar, a, t, &rc, X);     /* empty record: flagged, no NaN crash */
+    printf("version %d solve_status %d\n", symmicp_version(), st);
+    st = symmicp_create(&cfg, &ctx);
+    printf("create_status %d ctx %s\n", st, ctx ? "set" : "null");
+    if (st == SYMMICP_OK) symmicp_destroy(ctx);
+    return 0;
+}
+''')
+    exe = tmp_path / "abi_c"
+    libdir = os.path.dirname(sym.LIB_PATH)
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe),
+                        "-L", libdir, "-lsymmicp", "-Wl,-rpath," + libdir], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, (r.stdout, r.stderr)
+    assert "version 100" in r.stdout
+    import torch
+    if not torch.cuda.is_available():
+        assert "create_status" in r.stdout and "ctx null" in r.stdout and "create_status 0" not in r.stdout
