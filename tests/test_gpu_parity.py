@@ -557,6 +557,32 @@ def test_randomised_exactness_sweep(sym, oracle):
     assert cases == 60 and not failures, failures[:3]
 
 
+def test_bench_line_keeps_its_contract():
+    """bench.py on a small workload: ONE JSON line with the keys the driver reads, a roofline object whose achieved
+    figure is algorithmic bytes / measured kernel time, and a cpu_baseline object from the oracle."""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--points", "20000", "--steps", "6", "--warmup", "2"],
+                       capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["metric"] == "icp_iterations_per_sec" and d["unit"] == "iter/s" and d["n_gpus"] == 1 and d["steps"] == 6 and d["warmup"] == 2
+    assert d["higher_is_better"] is True and d["vs_baseline"] is None and d["data"] == "synthetic" and "workload" in d["config"]
+    assert abs(d["value"] - 1000.0 / d["ms_per_step"]) < 1e-2 * d["value"]
+    rf = d["roofline"]
+    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-4
+    assert abs(rf["achieved"] - rf["algorithmic_bytes_per_launch"] / (rf["kernel_ms"] * 1e-3) / 1e9) < 1e-2 * rf["achieved"]
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0 and cb["unit"] == "iter/s" and cb["sample"]
+
+
 def test_forced_repair_path_in_a_subprocess(sym):
     """SYMMICP_OPTIMISTIC=1 makes every pass skip the tree walk and repair itself afterwards if a query needed it (the
     switch is read once per process, hence the child process): the multi-pass exactness tests must still hold."""
