@@ -113,7 +113,7 @@ struct symmicp_ctx {
     uint32_t *src_order = nullptr;   // share position -> row in the caller's cloud (null = identity)
     int32_t *pos = nullptr;
     float *d2 = nullptr;
-    float *cert = nullptr;           // TREE: ref_x, ref_y, ref_z, slack (4 planar arrays)
+    float *cert = nullptr;           // TREE pair certificates: ref_x, ref_y, ref_z, clear radius (4 planar arrays)
     unsigned long long *best64 = nullptr;
     uint32_t *worklist = nullptr, *wl_count = nullptr;   // the sharded work list + its counters
     WorkLists wl{};

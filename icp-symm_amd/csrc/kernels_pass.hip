@@ -403,10 +403,11 @@ __device__ __forceinline__ uint32_t oct_walk(const TargetIndex &ix, float px, fl
 
 // ---------------------------------------------------------------------------
 // The nearest-neighbour pass (SYMMICP_CORR_TREE) is three kernels plus the final reduce:
-//   k_search_cells  thread = query: pair certificate / cell scan / 27-cell probe; what it cannot finish goes to a
-//                   work list (64-shard append list)
+//   k_search_cells  thread = query: pair certificate / cell scan / two-round cell probe; what it cannot finish goes
+//                   to a work list (64-shard append list)
 //   k_search_walk   the work list: one thread per entry on the sparse octree (long lists: the first pass), or one
-//                   wave per entry on the run tree (short lists: stragglers)
+//                   wave per entry on the run tree (short lists: stragglers).  Not launched after a pass whose list
+//                   was empty; the host repairs the pass if the list turns out non-empty (engine.cpp, run_pass)
 //   k_accumulate    streaming: rows + 37 fp64 sums from the stored pairs (and the optional write-back)
 // Blocks are dealt to XCDs round-robin, so block b is remapped to a contiguous chunk of the Morton-sorted source
 // per XCD: each XCD's 4 MB L2 then serves one compact region of the target.
@@ -784,7 +785,7 @@ __global__ __launch_bounds__(kPassThreads) void k_search_cells(PassArgs a, Targe
 // __ballot + popcount.  The pruning radius is min(best real candidate, smallest max-distance of any
 // box seen) -- a non-empty box guarantees a point within its farthest corner.  Leaves: 8 leaves x 8
 // points per batch, wave-wide argmin on (d2 bits << 32 | row).  If a frontier outgrows its LDS slot
-// the query is handed to the one-thread-per-query kernel instead (exact either way).
+// lane 0 finishes the query with the per-thread octree walk instead (exact either way).
 // ---------------------------------------------------------------------------
 
 __device__ __forceinline__ float boxmaxdist2(float px, float py, float pz, const float4 &lo, const float4 &hi)

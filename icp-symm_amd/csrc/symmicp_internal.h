@@ -99,7 +99,7 @@ struct PassArgs {
     double *partials;                   // [kNSum][blocks] (transposed)
     // pair certificates (TREE): position of the query when its pair was last searched, and how far it may move
     // before the pair has to be searched again (see k_search_cells)
-    float *ref_x, *ref_y, *ref_z, *slack;
+    float *ref_x, *ref_y, *ref_z, *slack;   // slack[i] = clear radius L around ref (0 = no certificate)
     int32_t use_slack;                  // 0 on the first pass of an alignment (certificates not valid yet)
 };
 
