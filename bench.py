@@ -44,6 +44,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=2, help="oracle iterations timed for cpu_baseline")
     ap.add_argument("--repeats", type=int, default=1, help="timed repetitions; the best is reported")
+    ap.add_argument("--exchange", default="rccl", choices=["rccl", "torch"],
+                    help="N>1: rccl = the library's own RCCL all-reduce (the product path); torch = external exchange, the 40-double "
+                         "record summed with torch.distributed.all_reduce between C calls (slow; lets the multi-rank scaffolding of "
+                         "this file run where RCCL cannot, e.g. several ranks on ONE GPU with --dist-backend gloo)")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"])
     args = ap.parse_args()
 
     import numpy as np
@@ -58,12 +63,17 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    if os.environ.get("SYMMICP_BENCH_DEVICE"):                 # rehearsal: every rank on the same GPU
+        local_rank = int(os.environ["SYMMICP_BENCH_DEVICE"])
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if args.dist_backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend="gloo")
 
     def barrier_sync():
         if dist is not None:
@@ -78,7 +88,9 @@ def main():
 
     eng = symmicp.Engine(device=local_rank, mode=getattr(symmicp, "MODE_" + args.mode.upper()),
                          corr=getattr(symmicp, "CORR_" + args.corr.upper()), max_iters=K, fixed_iters=1)
-    if world > 1:
+    if world > 1 and args.exchange == "torch":
+        eng.comm_init_rank(world, rank, None)                   # sharded, no communicator inside the library
+    elif world > 1:
         uid = [symmicp.comm_get_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(uid, src=0)
         eng.comm_init_rank(world, rank, uid[0])
@@ -92,6 +104,16 @@ def main():
     st0 = eng.stats()
 
     def run(k):
+        if world > 1 and args.exchange == "torch":
+            # external exchange: begin / k x (all-reduce of the record, set_sums, step), one C call per arrow
+            dev = "cuda" if args.dist_backend == "nccl" else "cpu"
+            it = eng.begin()
+            for _ in range(k):
+                t = torch.tensor(it["sums"], dtype=torch.float64, device=dev)
+                dist.all_reduce(t, op=dist.ReduceOp.SUM)
+                eng.set_sums(t.cpu().numpy())
+                it = eng.step()
+            return
         # begin + exactly k steps, inside one C call (symmicp_align with fixed_iters: myicp.cpp:122-142 without the stop rule)
         eng.set_config(max_iters=k)
         r = eng.align()
@@ -112,7 +134,7 @@ def main():
         barrier_sync()
         el = time.perf_counter() - t0
         if dist is not None:
-            t = torch.tensor([el], dtype=torch.float64, device="cuda")
+            t = torch.tensor([el], dtype=torch.float64, device="cuda" if args.dist_backend == "nccl" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el = float(t.item())
         st_timed = eng.stats()
@@ -196,7 +218,8 @@ def main():
             "config": {"workload": "%s: %d-pt synthetic cloud pair with normals, %d iters, %s mode, %s correspondences"
                                    % (args.workload.upper(), n_s, K, args.mode.upper(), args.corr),
                        "n_source": n_s, "n_target": n_t, "iters": K,
-                       "parallelism": "source sharded x%d, target replicated, 40-double RCCL all-reduce per pass" % world},
+                       "parallelism": "source sharded x%d, target replicated, 40-double %s all-reduce per pass"
+                                      % (world, "RCCL" if args.exchange == "rccl" else "torch.distributed(" + args.dist_backend + ")")},
             "mcorr_per_sec": round(n_s * K / elapsed / 1e6, 2),
             "ms_per_step_with_kernel_events": round(elapsed_instrumented / K * 1e3, 5),
             "final_transform_max_abs_err_vs_truth": err_truth,

@@ -583,6 +583,29 @@ def test_bench_line_keeps_its_contract():
     assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0 and cb["unit"] == "iter/s" and cb["sample"]
 
 
+def test_bench_multi_rank_scaffolding_on_one_gpu():
+    """bench.py under torch.distributed.run with TWO ranks, both on this one GPU (RCCL cannot do that, so the ranks
+    exchange their records through torch.distributed/gloo: --exchange torch): rank/world parsing, rendezvous on
+    127.0.0.1, sharded set_source on every rank, barrier + max-over-ranks timing, one JSON line from rank 0."""
+    import json
+    import socket
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, SYMMICP_BENCH_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2",
+                        "--points", "30000", "--exchange", "torch", "--dist-backend", "gloo"],
+                       capture_output=True, text=True, timeout=900, cwd=root, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 6 and d["value"] > 0 and d["cpu_baseline"] is None
+    assert d["final_transform_max_abs_err_vs_truth"] < 5e-3        # 6 iterations on a 30k-point pair: on its way to the truth
+    assert "x2" in d["config"]["parallelism"]
+
+
 def test_forced_repair_path_in_a_subprocess(sym):
     """SYMMICP_OPTIMISTIC=1 makes every pass skip the tree walk and repair itself afterwards if a query needed it (the
     switch is read once per process, hence the child process): the multi-pass exactness tests must still hold."""
