@@ -44,8 +44,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=2, help="oracle iterations timed for cpu_baseline")
     ap.add_argument("--repeats", type=int, default=1, help="timed repetitions; the best is reported")
-    ap.add_argument("--exchange", default="rccl", choices=["rccl", "torch"],
-                    help="N>1: rccl = the library's own RCCL all-reduce (the product path); torch = external exchange, the 40-double "
+    ap.add_argument("--exchange", default="rccl", choices=["rccl", "shm", "torch"],
+                    help="N>1: rccl = the library's own RCCL all-reduce (the default); shm = the library's shared-memory exchange "
+                         "(ranks of one node, no collective kernel); torch = external exchange, the 40-double "
                          "record summed with torch.distributed.all_reduce between C calls (slow; lets the multi-rank scaffolding of "
                          "this file run where RCCL cannot, e.g. several ranks on ONE GPU with --dist-backend gloo)")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"])
@@ -90,6 +91,10 @@ def main():
                          corr=getattr(symmicp, "CORR_" + args.corr.upper()), max_iters=K, fixed_iters=1)
     if world > 1 and args.exchange == "torch":
         eng.comm_init_rank(world, rank, None)                   # sharded, no communicator inside the library
+    elif world > 1 and args.exchange == "shm":
+        job = ["%s_%d" % (os.environ.get("MASTER_PORT", "0"), os.getpid()) if rank == 0 else None]
+        dist.broadcast_object_list(job, src=0)
+        eng.comm_init_shm(world, rank, job[0])
     elif world > 1:
         uid = [symmicp.comm_get_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(uid, src=0)
@@ -219,7 +224,7 @@ def main():
                                    % (args.workload.upper(), n_s, K, args.mode.upper(), args.corr),
                        "n_source": n_s, "n_target": n_t, "iters": K,
                        "parallelism": "source sharded x%d, target replicated, 40-double %s all-reduce per pass"
-                                      % (world, "RCCL" if args.exchange == "rccl" else "torch.distributed(" + args.dist_backend + ")")},
+                                      % (world, {"rccl": "RCCL", "shm": "shared-memory", "torch": "torch.distributed(" + args.dist_backend + ")"}[args.exchange])},
             "mcorr_per_sec": round(n_s * K / elapsed / 1e6, 2),
             "ms_per_step_with_kernel_events": round(elapsed_instrumented / K * 1e3, 5),
             "final_transform_max_abs_err_vs_truth": err_truth,

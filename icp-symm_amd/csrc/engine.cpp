@@ -9,6 +9,10 @@
 // There is no CPU fallback: without a HIP device every entry point fails loudly.
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -80,8 +84,27 @@ struct Arena {
     size_t cap = 0, off = 0;
 };
 
+// Intra-node exchange of the 40-double record through POSIX shared memory (symmicp_comm_init_shm): every rank spins on
+// its own GPU's record as in the single-GPU path, publishes it in its slot, waits for the other ranks' slots and adds
+// them up in rank order (so every rank gets bit-identical sums).  For a 320-byte latency-bound exchange this beats a
+// collective kernel launch; slots are double-buffered by exchange parity (a rank cannot be more than one exchange ahead).
+struct ShmSlot {
+    volatile unsigned long long seq;
+    double s[SYMMICP_NSUM];
+    char pad[512 - 8 - 8 * SYMMICP_NSUM];
+};
+static_assert(sizeof(ShmSlot) == 512, "slot = 4 cache lines");
+struct ShmExchange {
+    ShmSlot *slots = nullptr;        // [2][nranks]
+    size_t bytes = 0;
+    unsigned long long count = 0;    // exchanges done
+    std::string name;
+    bool owner = false;
+};
+
 struct symmicp_ctx {
     Arena arena;
+    ShmExchange shm;
     symmicp_config cfg{};
     int device = 0;
     hipStream_t stream = nullptr;
@@ -182,6 +205,8 @@ static void arena_begin(Arena &a, size_t want)
 // host-side timing of the pass loop, printed by symmicp_destroy under SYMMICP_DEBUG_HOST (debugging aid: process-wide, unsynchronised)
 static double g_t_launch = 0, g_t_spin = 0, g_t_between = 0, g_t_last_done = 0;
 static long g_n_pass = 0;
+
+static void shm_close(symmicp_ctx *c);
 
 static int fail(symmicp_ctx *c, int code, const std::string &msg)
 {
@@ -304,6 +329,7 @@ void symmicp_destroy(symmicp_ctx *c)
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
     if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
+    shm_close(c);
     free_target(c);
     free_source(c);
     hipFree(c->partials); hipFree(c->d_sums); hipFree(c->ticket); hipFree(c->arena.base);
@@ -712,6 +738,37 @@ static void flush_events(symmicp_ctx *c)
     c->ev_used = 0;
 }
 
+static void shm_close(symmicp_ctx *c)
+{
+    if (c->shm.slots) munmap((void *)c->shm.slots, c->shm.bytes);
+    if (c->shm.owner && !c->shm.name.empty()) shm_unlink(c->shm.name.c_str());
+    c->shm = ShmExchange{};
+}
+
+// rec[40]: this rank's record in, the sum over ranks out
+static int shm_exchange(symmicp_ctx *c, double *rec)
+{
+    ShmExchange &x = c->shm;
+    const unsigned long long k = ++x.count;
+    ShmSlot *buf = x.slots + (size_t)(k & 1ull) * c->nranks;
+    ShmSlot &mine = buf[c->rank];
+    for (int j = 0; j < kNSum; j++) mine.s[j] = rec[j];
+    __atomic_store_n(&mine.seq, k, __ATOMIC_RELEASE);
+    double tot[kNSum];
+    for (int j = 0; j < kNSum; j++) tot[j] = 0.0;
+    const double t0 = now_s();
+    for (int r = 0; r < c->nranks; r++) {
+        unsigned spins = 0;
+        while (__atomic_load_n(&buf[r].seq, __ATOMIC_ACQUIRE) != k) {
+            __builtin_ia32_pause();
+            if ((++spins & 0xFFFFu) == 0 && now_s() - t0 > 60.0) return fail(c, SYMMICP_ERR_COMM, "shared-memory exchange: a rank did not arrive within 60 s");
+        }
+        for (int j = 0; j < kNSum; j++) tot[j] += buf[r].s[j];
+    }
+    for (int j = 0; j < kNSum; j++) rec[j] = tot[j];
+    return SYMMICP_OK;
+}
+
 // ---- one pass over the source share ------------------------------------------------------------
 static int run_pass(symmicp_ctx *c, const float Xapply[16], bool from_cur, bool writeback, bool first)
 {
@@ -842,7 +899,8 @@ static int run_pass(symmicp_ctx *c, const float Xapply[16], bool from_cur, bool 
         return SYMMICP_OK;
     };
     if (int st = reduce_and_wait(optimistic ? 1 : 0)) return st;
-    // length of the work list (summed over ranks by the all-reduce, so every rank takes the same decision)
+    if (c->shm.slots) { if (int st = shm_exchange(c, c->h_sums)) return st; }
+    // length of the work list (summed over ranks by the exchange, so every rank takes the same decision)
     long long list_len = (c->cfg.corr == SYMMICP_CORR_TREE) ? (long long)c->h_sums[kNSum - 1] : -1;
     if (optimistic && list_len > 0) {
         // the walk was skipped but some queries needed it: their pairs are provisional, so are the sums
@@ -850,6 +908,7 @@ static int run_pass(symmicp_ctx *c, const float Xapply[16], bool from_cur, bool 
         launch_pass_tree_split(a, c->ix, c->wl, blocks, list_len <= 50000 ? 8192u : 0u, 2, c->stream, nullptr);
         if (ev && c->ev_split[c->ev_used] != 2) hipEventRecord(ev[4], c->stream);
         if (int st = reduce_and_wait(0)) return st;
+        if (c->shm.slots) { if (int st = shm_exchange(c, c->h_sums)) return st; }
     }
     if (ev) c->ev_used++;
     g_t_last_done = now_s(); g_n_pass++;
@@ -1150,6 +1209,48 @@ int symmicp_comm_init_rank(symmicp_ctx *c, int nranks, int rank, const void *uid
     std::memcpy(&id, uid, SYMMICP_UNIQUE_ID_BYTES);
     int r = g_rccl.CommInitRank(&c->comm, nranks, id, rank);
     if (r != 0) return fail(c, SYMMICP_ERR_COMM, std::string("ncclCommInitRank: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?"));
+    c->nranks = nranks;
+    c->rank = rank;
+    c->external_exchange = false;
+    return SYMMICP_OK;
+}
+
+int symmicp_comm_init_shm(symmicp_ctx *c, int nranks, int rank, const char *job_name)
+{
+    if (!c) return SYMMICP_ERR_ARG;
+    if (nranks < 1 || rank < 0 || rank >= nranks || !job_name || !*job_name) return fail(c, SYMMICP_ERR_ARG, "bad rank/nranks/name");
+    if (c->src0_block) return fail(c, SYMMICP_ERR_STATE, "attach the exchange before symmicp_set_source");
+    if (c->comm || c->shm.slots) return fail(c, SYMMICP_ERR_STATE, "a communicator is already attached");
+    std::string name = std::string("/symmicp_") + job_name;
+    for (char &ch : name) if (ch == '/' && &ch != &name[0]) ch = '_';
+    const size_t bytes = sizeof(ShmSlot) * 2 * (size_t)nranks;
+    int fd = -1;
+    if (rank == 0) {
+        shm_unlink(name.c_str());                                  // a leftover of a crashed job with the same name
+        fd = shm_open(name.c_str(), O_CREAT | O_EXCL | O_RDWR, 0600);
+        if (fd >= 0 && ftruncate(fd, (off_t)bytes) != 0) { close(fd); shm_unlink(name.c_str()); fd = -1; }
+    } else {
+        // wait for rank 0 to create and size the segment
+        const double t0 = now_s();
+        while (now_s() - t0 < 60.0) {
+            fd = shm_open(name.c_str(), O_RDWR, 0600);
+            if (fd >= 0) {
+                struct stat sb;
+                if (fstat(fd, &sb) == 0 && (size_t)sb.st_size >= bytes) break;
+                close(fd); fd = -1;
+            }
+            usleep(1000);
+        }
+    }
+    if (fd < 0) return fail(c, SYMMICP_ERR_COMM, "cannot open shared-memory segment " + name);
+    void *p = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    close(fd);
+    if (p == MAP_FAILED) return fail(c, SYMMICP_ERR_COMM, "mmap of " + name + " failed");
+    c->shm.slots = static_cast<ShmSlot *>(p);
+    c->shm.bytes = bytes;
+    c->shm.name = name;
+    c->shm.owner = (rank == 0);
+    c->shm.count = 0;
     c->nranks = nranks;
     c->rank = rank;
     c->external_exchange = false;

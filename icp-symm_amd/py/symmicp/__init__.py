@@ -72,7 +72,7 @@ EXPORTS = [
     "symmicp_version", "symmicp_set_source", "symmicp_set_target", "symmicp_align", "symmicp_begin", "symmicp_step",
     "symmicp_get_transform", "symmicp_get_pivot", "symmicp_get_correspondences", "symmicp_get_source",
     "symmicp_local_source_count", "symmicp_local_source_offset", "symmicp_solve", "symmicp_comm_get_unique_id",
-    "symmicp_comm_init_rank", "symmicp_set_sums", "symmicp_shard_range", "symmicp_get_stats", "symmicp_reset_stats", "symmicp_enable_timing",
+    "symmicp_comm_init_rank", "symmicp_set_sums", "symmicp_comm_init_shm", "symmicp_shard_range", "symmicp_get_stats", "symmicp_reset_stats", "symmicp_enable_timing",
     "symmicp_pcd_read", "symmicp_pcd_write", "symmicp_estimate_normals",
 ]
 
@@ -127,6 +127,7 @@ def lib():
     L.symmicp_comm_get_unique_id.argtypes = [vp]
     L.symmicp_comm_init_rank.argtypes = [vp, C.c_int, C.c_int, vp]
     L.symmicp_set_sums.argtypes = [vp, C.POINTER(Sums)]
+    L.symmicp_comm_init_shm.argtypes = [vp, C.c_int, C.c_int, C.c_char_p]
     L.symmicp_shard_range.argtypes = [C.c_size_t, C.c_int, C.c_int, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
     L.symmicp_get_stats.argtypes = [vp, C.POINTER(Stats)]
     L.symmicp_reset_stats.argtypes = [vp]
@@ -273,6 +274,10 @@ class Engine:
     def comm_init_rank(self, nranks, rank, uid):
         buf = C.create_string_buffer(uid, UNIQUE_ID_BYTES) if uid is not None else None
         self._chk(self._L.symmicp_comm_init_rank(self._h, nranks, rank, C.cast(buf, C.c_void_p) if buf else None))
+
+    def comm_init_shm(self, nranks, rank, job_name):
+        """ranks of one node: exchange the per-pass record through POSIX shared memory instead of RCCL"""
+        self._chk(self._L.symmicp_comm_init_shm(self._h, nranks, rank, str(job_name).encode()))
 
     def set_sums(self, total):
         """external exchange (comm_init_rank(nranks, rank, None)): hand the record summed over all ranks back before step()"""

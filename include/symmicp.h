@@ -183,6 +183,11 @@ int symmicp_comm_init_rank(symmicp_ctx *ctx, int nranks, int rank, const void *u
  * step; all ranks must pass the same 40 doubles so that their solves agree.  (symmicp_align is not available in this
  * mode: it would solve from the local record.) */
 int symmicp_set_sums(symmicp_ctx *ctx, const symmicp_sums *total_over_ranks);
+/* Ranks of ONE node can also exchange the record through POSIX shared memory instead of RCCL (a 320-byte, purely
+ * latency-bound exchange: no collective kernel, no extra launch).  job_name must be the same on all ranks and unique
+ * per job (it names the segment /symmicp_<job_name>; rank 0 creates and, on destroy, removes it).  Call it instead of
+ * symmicp_comm_init_rank, before symmicp_set_source; everything else (align, step, ...) works as with RCCL. */
+int symmicp_comm_init_shm(symmicp_ctx *ctx, int nranks, int rank, const char *job_name);
 
 /* ---- measurement helpers ------------------------------------------------ */
 typedef struct {
