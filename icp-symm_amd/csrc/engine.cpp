@@ -292,7 +292,7 @@ int symmicp_create(const symmicp_config *cfg, symmicp_ctx **out)
               hipHostGetDevicePointer((void **)&c->h_sums_dev, c->h_sums, 0) == hipSuccess &&
               std::memset(c->h_sums, 0, sizeof(double) * (kNSum + 8)) != nullptr &&
               true;
-    for (int k = 0; ok && k < symmicp_ctx::kEvRing * symmicp_ctx::kEvPer; k++) ok = hipEventCreate(&c->ev[k]) == hipSuccess;
+    for (int k = 0; ok && k < symmicp_ctx::kEvRing * symmicp_ctx::kEvPer; k++) ok = hipEventCreateWithFlags(&c->ev[k], hipEventDisableSystemFence) == hipSuccess;      // timing only: no system-scope cache flush per record
     if (!ok) { symmicp_destroy(c); return SYMMICP_ERR_HIP; }
     identity16(c->X);
     *out = c;
