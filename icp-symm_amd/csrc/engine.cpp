@@ -136,7 +136,7 @@ struct symmicp_ctx {
     uint32_t *src_order = nullptr;   // share position -> row in the caller's cloud (null = identity)
     int32_t *pos = nullptr;
     float *d2 = nullptr;
-    float *cert = nullptr;           // TREE pair certificates: ref_x, ref_y, ref_z, clear radius (4 planar arrays)
+    float *cert = nullptr;           // TREE pair certificates: one float4 (ref.xyz, clear radius) per source point
     unsigned long long *best64 = nullptr;
     uint32_t *worklist = nullptr, *wl_count = nullptr;   // the sharded work list + its counters
     WorkLists wl{};
@@ -792,9 +792,7 @@ static int run_pass(symmicp_ctx *c, const float Xapply[16], bool from_cur, bool 
     a.d2_out = (c->cfg.corr == SYMMICP_CORR_IDENTITY) ? nullptr : c->d2;
     a.partials = c->partials;
     {
-        const uint32_t nl = c->n_loc > 0 ? c->n_loc : 1;
-        a.ref_x = c->cert; a.ref_y = c->cert ? c->cert + nl : nullptr; a.ref_z = c->cert ? c->cert + 2 * (size_t)nl : nullptr;
-        a.slack = c->cert ? c->cert + 3 * (size_t)nl : nullptr;
+        a.cert = reinterpret_cast<float4 *>(c->cert);
         a.use_slack = (!first && c->cert && !std::getenv("SYMMICP_NO_CERT")) ? 1 : 0;
     }
     int blocks = (int)((c->n_loc + kPassThreads - 1) / kPassThreads);

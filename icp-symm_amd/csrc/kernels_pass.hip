@@ -476,7 +476,7 @@ __device__ __forceinline__ float axis_gap2(float p, float origin, int c, float h
 //
 // Pair certificates.  The search ball is padded by D = kSlackFrac * h beyond the previous pair's distance, so after
 // the scan every target point other than the winner is known to be at least L = min(second-nearest scanned, bound + D)
-// away from the query position p_ref (the "clear radius", stored in PassArgs::slack; 0 = no certificate).  If the
+// away from the query position p_ref (the "clear radius", stored in PassArgs::cert[i].w; 0 = no certificate).  If the
 // query later sits at p with |p - p_ref| = delta, any other point is >= L - delta away from it, so while the winner's
 // current distance d1' satisfies d1' + delta < L the nearest neighbour is provably the same point and the scan is
 // skipped; only the distance is refreshed.  Once ICP has converged almost every pair is certified and the kernel is
@@ -516,7 +516,7 @@ __global__ __launch_bounds__(kPassThreads) void k_search_cells(PassArgs a, Targe
         const float x = a.in.x[i], y = a.in.y[i], z = a.in.z[i];
         const int32_t prev = a.pos_prev ? a.pos_prev[i] : -1;
         float clear = 0.0f, rx = 0.0f, ry = 0.0f, rz = 0.0f;                              // L (0: no certificate), p_ref
-        if (a.use_slack) { clear = a.slack[i]; rx = a.ref_x[i]; ry = a.ref_y[i]; rz = a.ref_z[i]; }
+        if (a.use_slack) { const float4 ce = a.cert[i]; rx = ce.x; ry = ce.y; rz = ce.z; clear = ce.w; }      // one 16-byte load
         px = xf_row(a.X.m + 0, x, y, z, 1.0f); py = xf_row(a.X.m + 4, x, y, z, 1.0f); pz = xf_row(a.X.m + 8, x, y, z, 1.0f);
         if (prev >= 0 && (uint32_t)prev < ix.n) {
             const float4 q = ix.tq[prev];
@@ -623,7 +623,7 @@ __global__ __launch_bounds__(kPassThreads) void k_search_cells(PassArgs a, Targe
             if (defer) {
                 a.pos_out[i] = b.pos;        // provisional: the tree walk starts from this bound
                 a.d2_out[i] = b.d2;
-                a.slack[i] = 0.0f;           // pairs found by the walk carry no certificate
+                a.cert[i].w = 0.0f;           // pairs found by the walk carry no certificate
                 sl_push(wl.work, shard, i);
             }
         }
@@ -763,14 +763,13 @@ __global__ __launch_bounds__(kPassThreads) void k_search_cells(PassArgs a, Targe
         a.d2_out[i] = d1sq;
         if (probe && !(d1 < lim)) {
             // the probe could not prove its best: the tree walk takes over from this (tighter) bound
-            a.slack[i] = 0.0f;
+            a.cert[i].w = 0.0f;
             sl_push(wl.work, shard, i);
         } else {
             // certificate for the following passes
             const float second = sqrtf(__uint_as_float(s_second[tid])) * 0.99999f;
             const float L = fminf(second, lim * 0.99999f);
-            a.ref_x[i] = px; a.ref_y[i] = py; a.ref_z[i] = pz;
-            a.slack[i] = (L > d1) ? L : 0.0f;
+            a.cert[i] = make_float4(px, py, pz, (L > d1) ? L : 0.0f);
         }
     }
 }
@@ -952,8 +951,7 @@ __global__ __launch_bounds__(kWalkThreads, 6) void k_search_walk(PassArgs a, Tar
             // everything not scanned was pruned beyond (nearest + pad): same certificate as in k_search_cells
             const float d1 = sqrtf(__uint_as_float((uint32_t)(bkey >> 32)));
             const float L = fminf(sqrtf(__uint_as_float(second)), d1 + pad) * 0.99999f;
-            a.ref_x[i] = px; a.ref_y[i] = py; a.ref_z[i] = pz;
-            a.slack[i] = (L > d1 * 1.00001f) ? L : 0.0f;
+            a.cert[i] = make_float4(px, py, pz, (L > d1 * 1.00001f) ? L : 0.0f);
         }
         if (lane == 0) {
             a.pos_out[i] = bpos;

@@ -97,9 +97,9 @@ struct PassArgs {
     float *d2_out;                      // optional per-point squared distance (may be null)
     int32_t *pos_out;                   // sorted position / target row chosen this pass (may alias pos_prev)
     double *partials;                   // [kNSum][blocks] (transposed)
-    // pair certificates (TREE): position of the query when its pair was last searched, and how far it may move
-    // before the pair has to be searched again (see k_search_cells)
-    float *ref_x, *ref_y, *ref_z, *slack;   // slack[i] = clear radius L around ref (0 = no certificate)
+    // pair certificates (TREE): position of the query when its pair was last searched, and the radius around it known
+    // to hold no other target point (see k_search_cells)
+    float4 *cert;                       // per pair: (ref.xyz, clear radius L around ref; L = 0: no certificate)
     int32_t use_slack;                  // 0 on the first pass of an alignment (certificates not valid yet)
 };
 
