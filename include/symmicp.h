@@ -10,7 +10,8 @@
  * include/myicp.h.
  *
  * Threading: one ctx = one host thread = one GPU (one rank).  Multi-GPU runs
- * are one process (or thread) per GPU, joined by symmicp_comm_init_rank.
+ * are one process (or thread) per GPU, joined by symmicp_comm_init_rank (RCCL)
+ * or symmicp_comm_init_shm (ranks of one node).
  * Errors: every call returns SYMMICP_OK or an error code; the message is
  * available from symmicp_last_error().  The library never falls back to a
  * CPU path: without a usable HIP device symmicp_create fails.
@@ -36,7 +37,7 @@ typedef enum {
     SYMMICP_ERR_IO = 4,
     SYMMICP_ERR_HIP = 5,           /* HIP runtime error or no gfx950-capable device */
     SYMMICP_ERR_STATE = 6,         /* call out of order (e.g. step before begin) */
-    SYMMICP_ERR_COMM = 7           /* RCCL error */
+    SYMMICP_ERR_COMM = 7           /* RCCL or shared-memory exchange error */
 } symmicp_status;
 
 /* Arithmetic mode.  QUIRKS reproduces the reference exactly as written:
@@ -53,8 +54,10 @@ typedef enum { SYMMICP_MODE_QUIRKS = 0, SYMMICP_MODE_PAPER = 1, SYMMICP_MODE_P2P
 
 /* Correspondence.  IDENTITY is what the reference does (myicp.cpp:130, the
  * search is a todo at :128-131).  BRUTE and TREE are exact nearest neighbour
- * (ties -> lowest target index) by LDS-tiled brute force, or by the radix-
- * sorted Morton grid + implicit linear BVH built over the target. */
+ * (ties -> lowest target index) by LDS-tiled brute force, or by the index
+ * built over the Morton-sorted target (cell table + sparse octree; once an
+ * alignment has converged, per-pair certificates prove the pair unchanged and
+ * the search is skipped). */
 typedef enum { SYMMICP_CORR_IDENTITY = 0, SYMMICP_CORR_BRUTE = 1, SYMMICP_CORR_TREE = 2 } symmicp_corr;
 
 /* How the source is advanced.  INCREMENTAL rewrites source points and normals
