@@ -103,7 +103,9 @@ struct ShmExchange {
 };
 
 struct symmicp_ctx {
-    Arena arena;
+    Arena arena;                     // temporaries of one public call
+    Arena keep;                      // the target's persistent arrays (reused by the next set_target)
+    std::vector<void *> keep_extra;  // ... and those that did not fit
     ShmExchange shm;
     symmicp_config cfg{};
     int device = 0;
@@ -180,6 +182,9 @@ struct DevBuf {
     }
     T *release() { T *q = p; p = nullptr; return q; }           // (owned buffers only)
 };
+
+// persistent allocation for the target: from the context's keep-arena when it fits, else its own hipMalloc (tracked)
+static hipError_t keep_alloc(symmicp_ctx *c, void **out, size_t bytes);
 
 // rewind the arena and make sure it holds `want` bytes (contents are dead: called at the start of a public call)
 static void arena_begin(Arena &a, size_t want)
@@ -299,9 +304,24 @@ int symmicp_create(const symmicp_config *cfg, symmicp_ctx **out)
     return SYMMICP_OK;
 }
 
+static hipError_t keep_alloc(symmicp_ctx *c, void **out, size_t bytes)
+{
+    bytes = (bytes + 255) & ~(size_t)255;
+    if (!bytes) bytes = 256;
+    if (c->keep.base && c->keep.off + bytes <= c->keep.cap) { *out = c->keep.base + c->keep.off; c->keep.off += bytes; return hipSuccess; }
+    void *p = nullptr;
+    const hipError_t e = hipMalloc(&p, bytes);
+    if (e == hipSuccess) { c->keep_extra.push_back(p); *out = p; }
+    return e;
+}
+
 static void free_target(symmicp_ctx *c)
 {
-    hipFree(c->tgt_block); hipFree(c->tq); hipFree(c->tn); hipFree(c->boxes); hipFree(c->cells); hipFree(c->onodes); hipFree(c->ctop); hipFree(c->dbg);
+    // (the arrays live in the keep-arena, which stays allocated for the next target)
+    for (void *p : c->keep_extra) hipFree(p);
+    c->keep_extra.clear();
+    c->keep.off = 0;
+    hipFree(c->dbg);
     c->ctop = nullptr; c->dbg = nullptr; c->ix = TargetIndex{}; c->tgt_block = nullptr; c->tq = nullptr; c->tn = nullptr; c->boxes = nullptr; c->cells = nullptr; c->onodes = nullptr;
     c->have_index = false; c->n_t = 0;
 }
@@ -332,7 +352,7 @@ void symmicp_destroy(symmicp_ctx *c)
     shm_close(c);
     free_target(c);
     free_source(c);
-    hipFree(c->partials); hipFree(c->d_sums); hipFree(c->ticket); hipFree(c->arena.base);
+    hipFree(c->partials); hipFree(c->d_sums); hipFree(c->ticket); hipFree(c->arena.base); hipFree(c->keep.base);
     if (c->h_sums) hipHostFree(c->h_sums);
     for (hipEvent_t e : c->ev) if (e) hipEventDestroy(e);
     if (c->stream) hipStreamDestroy(c->stream);
@@ -368,7 +388,8 @@ static int upload_planar(symmicp_ctx *c, const float *xyz, size_t xr, size_t xc,
             for (int k = 0; k < 3; k++) s[k] += (double)xyz[i * xr + k * xc];
         for (int k = 0; k < 3; k++) centroid[k] = s[k] / (double)n;
     }
-    HIP_TRY(c, temp ? block.alloc_temp(c->arena, 6 * n) : block.alloc(6 * n));
+    if (temp) HIP_TRY(c, block.alloc_temp(c->arena, 6 * n));
+    else { HIP_TRY(c, keep_alloc(c, (void **)&block.p, sizeof(float) * 6 * n)); block.owned = false; }
     float *col[6];
     for (int k = 0; k < 6; k++) col[k] = block.p + (size_t)k * n;
     struct Part { const float *base; size_t rs, cs; int first_col; } parts[2] = {{xyz, xr, xc, 0}, {nrm, nr, nc, 3}};
@@ -447,7 +468,7 @@ static int build_octree(symmicp_ctx *c, const uint32_t *keys, const float4 *tq, 
     constexpr int NL = kMortonBits + 1;
     DevBuf<uint32_t> nid;                         // [NL][n]: id of the node that starts at point i, per level
     DevBuf<uint32_t> scan_ws, first;
-    DevBuf<float4> nodes;
+    float4 *nodes = nullptr;
     HIP_TRY(c, nid.alloc_temp(c->arena, (size_t)NL * n));
     HIP_TRY(c, scan_ws.alloc_temp(c->arena, (size_t)n / 2048 + 2));
     for (int l = 0; l < NL; l++) {
@@ -474,18 +495,18 @@ static int build_octree(symmicp_ctx *c, const uint32_t *keys, const float4 *tq, 
         // child_first is a 24-bit field (node word and walk stack word): targets beyond ~16.7M distinct finest cells are refused
         if (cnt[l] > 0xFFFFFFu) return fail(c, SYMMICP_ERR_SIZE, "octree level exceeds 2^24 nodes (target cloud too large for SYMMICP_CORR_TREE)");
     HIP_TRY(c, first.alloc_temp(c->arena, total + 1));
-    HIP_TRY(c, nodes.alloc(2 * total));
+    HIP_TRY(c, keep_alloc(c, (void **)&nodes, sizeof(float4) * 2 * total));
     for (int l = 0; l < NL; l++)
         launch_oct_first(keys, n, l, nid.p + (size_t)l * n, first.p + ix->olevel_off[l], c->stream);
     for (int l = NL - 1; l >= 0; l--) {
         const bool bottom = (l == NL - 1);
         launch_oct_nodes(l, tq, n, first.p + ix->olevel_off[l], cnt[l], bottom ? nullptr : nid.p + (size_t)(l + 1) * n,
-                         bottom ? 0u : cnt[l + 1], bottom ? nullptr : nodes.p + 2 * (size_t)ix->olevel_off[l + 1],
-                         nodes.p + 2 * (size_t)ix->olevel_off[l], c->stream);
+                         bottom ? 0u : cnt[l + 1], bottom ? nullptr : nodes + 2 * (size_t)ix->olevel_off[l + 1],
+                         nodes + 2 * (size_t)ix->olevel_off[l], c->stream);
     }
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     HIP_TRY(c, hipGetLastError());
-    *onodes_out = nodes.release();
+    *onodes_out = nodes;
     ix->onodes = *onodes_out;
     return SYMMICP_OK;
 }
@@ -544,9 +565,9 @@ static int build_index(symmicp_ctx *c, const CloudSoA &cl, uint32_t n, bool want
         const int tshift = 3 * (kMortonBits - ltop);
         const bool last_starts = (n == 1) || (tshift < 30 && (kl[1] >> tshift) != (kl[0] >> tshift));
         const size_t nblocks = (size_t)last_excl + (last_starts ? 1 : 0);
-        HIP_TRY(c, hipMalloc((void **)ctop_out, sizeof(uint32_t) * ntop));
+        HIP_TRY(c, keep_alloc(c, (void **)ctop_out, sizeof(uint32_t) * ntop));
         HIP_TRY(c, hipMemsetAsync(*ctop_out, 0xFF, sizeof(uint32_t) * ntop, c->stream));
-        HIP_TRY(c, hipMalloc((void **)cells_out, sizeof(uint2) * nblocks * 512));
+        HIP_TRY(c, keep_alloc(c, (void **)cells_out, sizeof(uint2) * nblocks * 512));
         HIP_TRY(c, hipMemsetAsync(*cells_out, 0, sizeof(uint2) * nblocks * 512, c->stream));
         launch_cell_table(keys.p, n, glevel, nid_top.p, *ctop_out, *cells_out, c->stream);
         HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -574,7 +595,7 @@ static int build_index(symmicp_ctx *c, const CloudSoA &cl, uint32_t n, bool want
     }
     ix.top = nl - 1;
     ix.ntop = cnt[nl - 1];
-    HIP_TRY(c, hipMalloc((void **)boxes_out, sizeof(float4) * 2 * total));
+    HIP_TRY(c, keep_alloc(c, (void **)boxes_out, sizeof(float4) * 2 * total));
     float4 *boxes = *boxes_out;
     launch_leaf_boxes(tq, n, boxes + 2 * (size_t)ix.level_off[0], pad[0], c->stream);
     for (int l = 1; l < nl; l++)
@@ -601,6 +622,16 @@ int symmicp_set_target(symmicp_ctx *c, const float *xyz, size_t xr, size_t xc, c
     const double t0 = now_s();
     free_target(c);
     c->begun = false;
+    {
+        // the target's persistent arrays: planar cloud 24 B, tq 16, pair records 32, octree ~64, run tree ~5, cell table
+        const size_t want = n * 160 + ((size_t)16 << 20);
+        if (c->keep.cap < want) {
+            hipFree(c->keep.base);
+            c->keep = Arena{};
+            if (hipMalloc((void **)&c->keep.base, want + want / 8) == hipSuccess) c->keep.cap = want + want / 8;
+            else (void)hipGetLastError();      // every keep_alloc then falls back to its own hipMalloc
+        }
+    }
     // temporaries of the upload and of the index build: ~80 B per point (11 octree-level id arrays, sort buffers, raw rows)
     arena_begin(c->arena, n * (96 + 4 * (xr + nr)) + ((size_t)1 << 20));
     double cen[3];
@@ -615,8 +646,8 @@ int symmicp_set_target(symmicp_ctx *c, const float *xyz, size_t xr, size_t xc, c
     if (c->cfg.corr == SYMMICP_CORR_IDENTITY) return SYMMICP_OK;
 
     const double t1 = now_s();
-    HIP_TRY(c, hipMalloc((void **)&c->tq, sizeof(float4) * n));
-    HIP_TRY(c, hipMalloc((void **)&c->tn, sizeof(float4) * 2 * n));      // (point, normal) pair records
+    HIP_TRY(c, keep_alloc(c, (void **)&c->tq, sizeof(float4) * n));
+    HIP_TRY(c, keep_alloc(c, (void **)&c->tn, sizeof(float4) * 2 * n));      // (point, normal) pair records
     if (c->cfg.corr == SYMMICP_CORR_BRUTE) {
         launch_iota_f4(c->tgt.x, c->tgt.y, c->tgt.z, c->tgt.nx, c->tgt.ny, c->tgt.nz, c->n_t, c->tq, c->tn, c->stream);
         HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -1138,8 +1169,8 @@ int symmicp_estimate_normals(int device, const float *xyz, size_t row_stride, si
     float4 *tq = nullptr, *tn = nullptr, *boxes = nullptr;
     uint2 *cells = nullptr;
     auto cleanup = [&]() {
-        hipFree(block); hipFree(d_nrm); hipFree(d_curv); hipFree(tq); hipFree(tn); hipFree(boxes); hipFree(cells);
-        symmicp_destroy(c);
+        hipFree(d_nrm); hipFree(d_curv);
+        symmicp_destroy(c);             // (block, tq, tn, boxes, cells belong to the context's keep-arena)
     };
     // the cloud has no normals yet: stage xyz twice (the normal slots are ignored)
     arena_begin(c->arena, n * (96 + 8 * row_stride) + ((size_t)1 << 20));
@@ -1152,7 +1183,7 @@ int symmicp_estimate_normals(int device, const float *xyz, size_t row_stride, si
     CloudSoA cl;
     soa_from_block(block, n, cl);
     TargetIndex ix{};
-    bool ok = hipMalloc((void **)&tq, sizeof(float4) * n) == hipSuccess && hipMalloc((void **)&tn, sizeof(float4) * 2 * n) == hipSuccess &&
+    bool ok = keep_alloc(c, (void **)&tq, sizeof(float4) * n) == hipSuccess && keep_alloc(c, (void **)&tn, sizeof(float4) * 2 * n) == hipSuccess &&
               hipMalloc((void **)&d_nrm, sizeof(float) * 3 * n) == hipSuccess && hipMalloc((void **)&d_curv, sizeof(float) * n) == hipSuccess;
     if (!ok) { cleanup(); return SYMMICP_ERR_HIP; }
     st = build_index(c, cl, (uint32_t)n, /*want_grid=*/false, tq, tn, &boxes, &cells, &ix, nullptr, nullptr);
