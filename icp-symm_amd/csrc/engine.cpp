@@ -138,6 +138,7 @@ struct symmicp_ctx {
     uint32_t *src_order = nullptr;   // share position -> row in the caller's cloud (null = identity)
     int32_t *pos = nullptr;
     float *d2 = nullptr;
+    float4 *pairrec = nullptr;       // TREE: per pair, its own copy of the target's (point, normal) record
     float *cert = nullptr;           // TREE pair certificates: one float4 (ref.xyz, clear radius) per source point
     unsigned long long *best64 = nullptr;
     uint32_t *worklist = nullptr, *wl_count = nullptr;   // the sharded work list + its counters
@@ -329,7 +330,7 @@ static void free_target(symmicp_ctx *c)
 static void forget_source(symmicp_ctx *c)
 {
     // (the arrays live in one block, c->src_all, which is kept for the next source of the same or a smaller size)
-    c->worklist = c->wl_count = nullptr; c->cert = nullptr;
+    c->worklist = c->wl_count = nullptr; c->cert = nullptr; c->pairrec = nullptr;
     c->src0_block = c->cur_block = nullptr; c->src_order = nullptr; c->pos = nullptr; c->d2 = nullptr; c->best64 = nullptr;
     c->n_loc = c->n_s_total = c->src_off = 0;
 }
@@ -698,6 +699,7 @@ int symmicp_set_source(symmicp_ctx *c, const float *xyz, size_t xr, size_t xc, c
     const size_t o_pos = take(sizeof(int32_t) * nl), o_d2 = take(sizeof(float) * nl);
     const size_t o_best = brute ? take(sizeof(unsigned long long) * nl) : 0;
     const size_t o_cert = tree ? take(sizeof(float) * 4 * nl) : 0;
+    const size_t o_prec = tree ? take(sizeof(float4) * 2 * nl) : 0;
     const size_t o_wl = tree ? take(sizeof(uint32_t) * per_list) : 0, o_cnt = tree ? take(sizeof(uint32_t) * ncount) : 0;
     if (off > c->src_all_cap) {
         hipFree(c->src_all);
@@ -733,6 +735,7 @@ int symmicp_set_source(symmicp_ctx *c, const float *xyz, size_t xr, size_t xc, c
     }
     if (tree) {
         c->cert = reinterpret_cast<float *>(c->src_all + o_cert);
+        c->pairrec = reinterpret_cast<float4 *>(c->src_all + o_prec);
         c->worklist = reinterpret_cast<uint32_t *>(c->src_all + o_wl);
         c->wl_count = reinterpret_cast<uint32_t *>(c->src_all + o_cnt);
         HIP_TRY(c, hipMemsetAsync(c->cert, 0, sizeof(float) * 4 * nl, c->stream));
@@ -824,6 +827,7 @@ static int run_pass(symmicp_ctx *c, const float Xapply[16], bool from_cur, bool 
     a.partials = c->partials;
     {
         a.cert = reinterpret_cast<float4 *>(c->cert);
+        a.pairrec = c->pairrec;
         a.use_slack = (!first && c->cert && !std::getenv("SYMMICP_NO_CERT")) ? 1 : 0;
     }
     int blocks = (int)((c->n_loc + kPassThreads - 1) / kPassThreads);

@@ -454,6 +454,17 @@ __device__ __forceinline__ uint32_t xcd_remap(uint32_t b, uint32_t nb_padded)
     return (b & 7u) * (nb_padded >> 3) + (b >> 3);
 }
 
+// Every pair keeps a private copy of its target's 32-byte (point, normal) record, so that k_accumulate streams instead of
+// gathering through `pos`: once an alignment has converged almost no pair changes, and the gather was what bounded
+// that kernel.  k_search_cells refreshes the copy of a pair it settles itself and marks the copy STALE (w = 2 in the
+// normal slot) when it hands the query to the tree walk; k_accumulate then gathers that pair once more and refreshes the
+// copy itself (the walk kernel is register-bound and stays untouched).  w = 1: the point has no target at all.
+__device__ __forceinline__ void store_pair_record(const PassArgs &a, const TargetIndex &ix, uint32_t i, int32_t pos)
+{
+    a.pairrec[2 * (size_t)i] = ix.tn[2 * (size_t)pos];
+    a.pairrec[2 * (size_t)i + 1] = ix.tn[2 * (size_t)pos + 1];
+}
+
 // squared gap (minus the safety margin) between the query coordinate and the cell [lo, lo+h) on one axis
 __device__ __forceinline__ float axis_gap2(float p, float origin, int c, float h, float margin)
 {
@@ -624,6 +635,7 @@ __global__ __launch_bounds__(kPassThreads) void k_search_cells(PassArgs a, Targe
                 a.pos_out[i] = b.pos;        // provisional: the tree walk starts from this bound
                 a.d2_out[i] = b.d2;
                 a.cert[i].w = 0.0f;           // pairs found by the walk carry no certificate
+                a.pairrec[2 * (size_t)i + 1].w = 2.0f;      // ... and k_accumulate has to fetch their record again
                 sl_push(wl.work, shard, i);
             }
         }
@@ -764,12 +776,14 @@ __global__ __launch_bounds__(kPassThreads) void k_search_cells(PassArgs a, Targe
         if (probe && !(d1 < lim)) {
             // the probe could not prove its best: the tree walk takes over from this (tighter) bound
             a.cert[i].w = 0.0f;
+            a.pairrec[2 * (size_t)i + 1].w = 2.0f;
             sl_push(wl.work, shard, i);
         } else {
             // certificate for the following passes
             const float second = sqrtf(__uint_as_float(s_second[tid])) * 0.99999f;
             const float L = fminf(second, lim * 0.99999f);
             a.cert[i] = make_float4(px, py, pz, (L > d1) ? L : 0.0f);
+            store_pair_record(a, ix, i, s_pos[tid]);
         }
     }
 }
@@ -974,7 +988,14 @@ __global__ __launch_bounds__(kPassThreads) void k_accumulate(PassArgs a, const f
         if (i >= a.n) continue;
         const float x = a.in.x[i], y = a.in.y[i], z = a.in.z[i];
         const float nx = a.in.nx[i], ny = a.in.ny[i], nz = a.in.nz[i];
-        const int32_t pos = a.pos_out[i];
+        float4 q = a.pairrec[2 * (size_t)i], nq = a.pairrec[2 * (size_t)i + 1];            // the pair's own copy: coalesced
+        if (nq.w == 2.0f) {
+            // stale copy: the pair went through the tree walk this pass
+            const int32_t pos = a.pos_out[i];
+            if (pos >= 0) { q = tn[2 * (size_t)pos]; nq = tn[2 * (size_t)pos + 1]; }
+            else nq = make_float4(0.f, 0.f, 0.f, 1.f);
+            if (a.refresh_records) { a.pairrec[2 * (size_t)i] = q; a.pairrec[2 * (size_t)i + 1] = nq; }
+        }
         const float px = xf_row(a.X.m + 0, x, y, z, 1.0f), py = xf_row(a.X.m + 4, x, y, z, 1.0f), pz = xf_row(a.X.m + 8, x, y, z, 1.0f);
         const float npx = xf_row(a.X.m + 0, nx, ny, nz, a.X.nrm_w), npy = xf_row(a.X.m + 4, nx, ny, nz, a.X.nrm_w),
                     npz = xf_row(a.X.m + 8, nx, ny, nz, a.X.nrm_w);
@@ -982,8 +1003,7 @@ __global__ __launch_bounds__(kPassThreads) void k_accumulate(PassArgs a, const f
             a.out.x[i] = px; a.out.y[i] = py; a.out.z[i] = pz;
             a.out.nx[i] = npx; a.out.ny[i] = npy; a.out.nz[i] = npz;
         }
-        if (pos < 0) continue;
-        const float4 q = tn[2 * (size_t)pos], nq = tn[2 * (size_t)pos + 1];     // one 32-byte pair record
+        if (nq.w != 0.0f) continue;                       // no target for this point
         const float d2 = dist2(px, py, pz, q.x, q.y, q.z);
         if (a.max_d2 > 0.0f && d2 > a.max_d2) continue;
         if (a.min_ndot > -1.0f && (npx * nq.x + npy * nq.y) + npz * nq.z < a.min_ndot) continue;
@@ -1168,9 +1188,11 @@ uint32_t walk_blocks_full(const WorkLists &wl)
 
 // stage: 0 = whole pass (cells, walk, accumulate); 1 = cells and accumulate only (the host expects an empty work list
 // and repairs the pass otherwise); 2 = the repair: walk and accumulate
-void launch_pass_tree_split(const PassArgs &a, const TargetIndex &ix, const WorkLists &wl, int acc_blocks, uint32_t walk_blocks,
+void launch_pass_tree_split(const PassArgs &a_in, const TargetIndex &ix, const WorkLists &wl, int acc_blocks, uint32_t walk_blocks,
                             int stage, hipStream_t s, hipEvent_t *ev)
 {
+    PassArgs a = a_in;
+    a.refresh_records = (stage != 1) ? 1 : 0;      // a stage-1 pass may still be repaired: its accumulate must not settle stale copies
     static const uint32_t wave_mode_max = getenv("SYMMICP_WAVE_MODE_MAX") ? (uint32_t)atol(getenv("SYMMICP_WAVE_MODE_MAX")) : 200000u;   // work lists longer than this use one thread per query
     // all shard counters are zero here: cleared by the previous pass's final reduce
     const uint32_t nb = (a.n + kPassThreads - 1) / kPassThreads;

@@ -99,6 +99,8 @@ struct PassArgs {
     double *partials;                   // [kNSum][blocks] (transposed)
     // pair certificates (TREE): position of the query when its pair was last searched, and the radius around it known
     // to hold no other target point (see k_search_cells)
+    float4 *pairrec;                    // TREE: per pair, its own copy of the target's (point, normal) record (2 float4)
+    int32_t refresh_records;            // k_accumulate may replace stale copies (0 in a pass that may still be repaired)
     float4 *cert;                       // per pair: (ref.xyz, clear radius L around ref; L = 0: no certificate)
     int32_t use_slack;                  // 0 on the first pass of an alignment (certificates not valid yet)
 };
