@@ -491,8 +491,12 @@ __device__ __forceinline__ float axis_gap2(float p, float origin, int c, float h
 // query later sits at p with |p - p_ref| = delta, any other point is >= L - delta away from it, so while the winner's
 // current distance d1' satisfies d1' + delta < L the nearest neighbour is provably the same point and the scan is
 // skipped; only the distance is refreshed.  Once ICP has converged almost every pair is certified and the kernel is
-// little more than phase 1.  Margins of 1e-5 relative cover fp32 rounding (distance evaluations are good to ~4e-7);
-// exact ties give L <= d1, i.e. no certificate, and are always searched again.
+// little more than phase 1.  Margins: every fp32 distance here is good to ~2.5e-7 relative (three differences, three
+// squares, two sums, one 1-ulp root), so with D(p,x) >= second (1 - 2.5e-7) - delta (1 + 2.5e-7) for every other point x
+// the test (d1' + delta) (1 + 2e-6) < second (1 - 1e-6) leaves D(p,x) > D(p,winner) (1 + 2e-6): the fp32 comparison the
+// oracle makes cannot come out the other way (it needs 3.5e-7).  Bounds that come from cell faces (lim) carry the
+// grid's own absolute margin and keep 1e-5.  Pairs whose two nearest points are closer together than that - a few
+// dozen per million - have no certificate and are searched again in every pass.
 // ---------------------------------------------------------------------------
 constexpr float kSlackFrac = 0.25f;
 
@@ -538,7 +542,7 @@ __global__ __launch_bounds__(kPassThreads) void k_search_cells(PassArgs a, Targe
         bool certified = false;
         if (a.use_slack && b.pos >= 0) {
             const float m2 = dist2(px, py, pz, rx, ry, rz);                               // delta^2
-            certified = (__builtin_amdgcn_sqrtf(b.d2) + __builtin_amdgcn_sqrtf(m2)) * 1.00002f < clear;      // 1-ulp roots, inside the margin
+            certified = (__builtin_amdgcn_sqrtf(b.d2) + __builtin_amdgcn_sqrtf(m2)) * 1.000002f < clear;     // 1-ulp roots, inside the margin
         }
         if (certified) {
             a.d2_out[i] = b.d2;          // same pair, refreshed distance; position, certificate unchanged
@@ -770,7 +774,7 @@ __global__ __launch_bounds__(kPassThreads) void k_search_cells(PassArgs a, Targe
     if (active && (searched || probe)) {
         const unsigned long long key = s_key[tid];
         const float d1sq = __uint_as_float((uint32_t)(key >> 32));
-        const float d1 = sqrtf(d1sq) * 1.00001f;
+        const float d1 = sqrtf(d1sq) * 1.000001f;
         a.pos_out[i] = s_pos[tid];
         a.d2_out[i] = d1sq;
         if (probe && !(d1 < lim)) {
@@ -780,7 +784,7 @@ __global__ __launch_bounds__(kPassThreads) void k_search_cells(PassArgs a, Targe
             sl_push(wl.work, shard, i);
         } else {
             // certificate for the following passes
-            const float second = sqrtf(__uint_as_float(s_second[tid])) * 0.99999f;
+            const float second = sqrtf(__uint_as_float(s_second[tid])) * 0.999999f;
             const float L = fminf(second, lim * 0.99999f);
             a.cert[i] = make_float4(px, py, pz, (L > d1) ? L : 0.0f);
             store_pair_record(a, ix, i, s_pos[tid]);
@@ -964,8 +968,8 @@ __global__ __launch_bounds__(kWalkThreads, 6) void k_search_walk(PassArgs a, Tar
         if (lane == 0 && bkey != ~0ull) {
             // everything not scanned was pruned beyond (nearest + pad): same certificate as in k_search_cells
             const float d1 = sqrtf(__uint_as_float((uint32_t)(bkey >> 32)));
-            const float L = fminf(sqrtf(__uint_as_float(second)), d1 + pad) * 0.99999f;
-            a.cert[i] = make_float4(px, py, pz, (L > d1 * 1.00001f) ? L : 0.0f);
+            const float L = fminf(sqrtf(__uint_as_float(second)) * 0.999999f, (d1 + pad) * 0.99999f);
+            a.cert[i] = make_float4(px, py, pz, (L > d1 * 1.000001f) ? L : 0.0f);
         }
         if (lane == 0) {
             a.pos_out[i] = bpos;
