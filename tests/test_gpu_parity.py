@@ -606,6 +606,24 @@ def test_bench_multi_rank_scaffolding_on_one_gpu():
     assert "x2" in d["config"]["parallelism"]
 
 
+def test_rccl_bootstrap_between_two_ranks_reaches_the_device_check():
+    """bench.py's default exchange with two ranks: rank 0's RCCL unique id travels to rank 1, both call ncclCommInitRank
+    and finish RCCL's bootstrap exchange -- and because this box has ONE GPU, RCCL then refuses the duplicate device
+    ("invalid usage").  The library must report that as SYMMICP_ERR_COMM on both ranks, quickly, instead of hanging;
+    on a real multi-GPU node the same sequence yields the communicator."""
+    import socket
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, SYMMICP_BENCH_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1",
+                        "--points", "20000", "--exchange", "rccl", "--dist-backend", "gloo", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=300, cwd=root, env=env)
+    assert r.returncode != 0
+    assert "ERR_COMM" in r.stderr and "ncclCommInitRank" in r.stderr, r.stderr[-2000:]
+
+
 def _shm_rank(rank, world, job, outdir):
     import numpy as np
     import symmicp as sym
