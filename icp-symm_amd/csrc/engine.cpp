@@ -700,7 +700,7 @@ int symmicp_set_source(symmicp_ctx *c, const float *xyz, size_t xr, size_t xc, c
     const size_t o_best = brute ? take(sizeof(unsigned long long) * nl) : 0;
     const size_t o_cert = tree ? take(sizeof(float) * 4 * nl) : 0;
     const size_t o_prec = tree ? take(sizeof(float4) * 2 * nl) : 0;
-    const size_t o_wl = tree ? take(sizeof(uint32_t) * per_list) : 0, o_cnt = tree ? take(sizeof(uint32_t) * ncount) : 0;
+    const size_t o_wl = tree ? take(sizeof(uint32_t) * 2 * per_list) : 0, o_cnt = tree ? take(sizeof(uint32_t) * 2 * ncount) : 0;      // work + retry lists
     if (off > c->src_all_cap) {
         hipFree(c->src_all);
         c->src_all = nullptr; c->src_all_cap = 0;
@@ -739,8 +739,9 @@ int symmicp_set_source(symmicp_ctx *c, const float *xyz, size_t xr, size_t xc, c
         c->worklist = reinterpret_cast<uint32_t *>(c->src_all + o_wl);
         c->wl_count = reinterpret_cast<uint32_t *>(c->src_all + o_cnt);
         HIP_TRY(c, hipMemsetAsync(c->cert, 0, sizeof(float) * 4 * nl, c->stream));
-        HIP_TRY(c, hipMemsetAsync(c->wl_count, 0, sizeof(uint32_t) * ncount, c->stream));
+        HIP_TRY(c, hipMemsetAsync(c->wl_count, 0, sizeof(uint32_t) * 2 * ncount, c->stream));
         c->wl.work = ShardList{c->worklist, c->wl_count, cap};
+        c->wl.retry = ShardList{c->worklist + per_list, c->wl_count + ncount, cap};
     }
     HIP_TRY(c, hipStreamSynchronize(c->stream));       // (the arena-backed upload is read by the gather above)
     HIP_TRY(c, hipGetLastError());
@@ -828,6 +829,9 @@ static int run_pass(symmicp_ctx *c, const float Xapply[16], bool from_cur, bool 
     {
         a.cert = reinterpret_cast<float4 *>(c->cert);
         a.pairrec = c->pairrec;
+        // sharded runs: the first pass over a small share is bound by its slowest walks, not by throughput
+        static const char *bw_env = std::getenv("SYMMICP_BUDGET_WALK");        // "0" never, "1" always (tests), unset: auto
+        a.budget_walk = bw_env ? (bw_env[0] == '1') : (first && c->nranks > 1 && c->n_loc < 400000u);
         a.use_slack = (!first && c->cert && !std::getenv("SYMMICP_NO_CERT")) ? 1 : 0;
     }
     int blocks = (int)((c->n_loc + kPassThreads - 1) / kPassThreads);

@@ -317,7 +317,11 @@ struct OctStack {
 // are read as degenerate boxes (lo = hi = point), for which boxdist2 is bit-for-bit dist2.  Lanes of a wave sit at
 // different nodes of different kinds, but now they all execute one common body (load <= 8 entities, 8 distances)
 // instead of serialising a leaf path, an internal path and a sibling path each trip.
-__device__ __forceinline__ uint32_t oct_walk(const TargetIndex &ix, float px, float py, float pz, Best &b)
+// BUDGETED: give up after `budget` node visits (return value > budget); b then holds the best point seen so far, a valid
+// bound for whoever finishes the query.  The plain instantiation carries no trace of it (the walk kernel is
+// register-bound: the extra state costs the unbudgeted walk 4 %).
+template <bool BUDGETED = false>
+__device__ __forceinline__ uint32_t oct_walk(const TargetIndex &ix, float px, float py, float pz, Best &b, uint32_t budget = 0xFFFFFFFFu)
 {
     const float inf = __int_as_float(0x7f800000);
     OctStack st;
@@ -328,6 +332,7 @@ __device__ __forceinline__ uint32_t oct_walk(const TargetIndex &ix, float px, fl
     uint32_t visits = 0;
     while (true) {
         visits++;
+        if (BUDGETED && visits > budget) return visits;
         const float4 *__restrict__ nd = ix.onodes + 2 * ((size_t)ix.olevel_off[L] + idx);
         const float4 hA = nd[0], hB = nd[1];
         const uint32_t first = (uint32_t)__float_as_int(hA.w);
@@ -837,25 +842,33 @@ __device__ __forceinline__ float wave_min_f32(float v)
 constexpr int kWalkThreads = 64;
 constexpr uint32_t kWaveWorkers = 8192;
 
-__global__ __launch_bounds__(kWalkThreads, 6) void k_search_walk(PassArgs a, TargetIndex ix, WorkLists wl, uint32_t kWaveModeMax)
+// BUDGETED instantiation (sharded runs, first pass of a small share): `list` is the list to drain (the work list, or the
+// retry list of the previous launch); in the one-thread-per-query regime a walk gets `budget` node visits, and what it
+// has not settled by then goes to wl.retry with the best point seen so far as its bound, for a second launch in the
+// wave-per-query regime.  Why: a wave is as slow as its slowest lane (471 visits against a mean of 81 on the 1M-point
+// surface pair), and with ~100k queries per rank that tail is the whole kernel.
+template <bool BUDGETED>
+__global__ __launch_bounds__(kWalkThreads, 6) void k_search_walk(PassArgs a, TargetIndex ix, WorkLists wl, ShardList list, uint32_t kWaveModeMax,
+                                                                 uint32_t budget)
 {
     __shared__ uint32_t fr[1][2][kWaveFrontier];
     __shared__ uint32_t pre[kShards + 1];
-    sl_prefix(wl.work, pre);
+    sl_prefix(list, pre);
     const float inf = __int_as_float(0x7f800000);
     if (pre[kShards] > kWaveModeMax) {
         // ---- long list: one thread per entry (the launcher normally sizes the grid so that this loop runs once) ----
         for (uint32_t g = blockIdx.x * kWalkThreads + threadIdx.x; ; g += gridDim.x * kWalkThreads) {
             uint32_t i;
-            if (!sl_locate(wl.work, pre, g, i)) break;
+            if (!sl_locate(list, pre, g, i)) break;
             const float x = a.in.x[i], y = a.in.y[i], z = a.in.z[i];
             const float px = xf_row(a.X.m + 0, x, y, z, 1.0f), py = xf_row(a.X.m + 4, x, y, z, 1.0f), pz = xf_row(a.X.m + 8, x, y, z, 1.0f);
             Best b;
             b.pos = a.pos_out[i]; b.d2 = a.d2_out[i]; b.row = 0x7fffffff;
             if (b.pos >= 0) b.row = __float_as_int(ix.tq[b.pos].w);
-            const uint32_t visits = oct_walk(ix, px, py, pz, b);
+            const uint32_t visits = oct_walk<BUDGETED>(ix, px, py, pz, b, budget);
             a.pos_out[i] = b.pos;
             a.d2_out[i] = b.d2;
+            if (BUDGETED && visits > budget) sl_push(wl.retry, blockIdx.x & (kShards - 1), i);      // unfinished: the wave regime takes over
             if (ix.dbg) {
                 uint32_t mx = visits;
                 for (int off = 32; off > 0; off >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, off, 64));
@@ -871,7 +884,7 @@ __global__ __launch_bounds__(kWalkThreads, 6) void k_search_walk(PassArgs a, Tar
     const uint32_t nwaves = min(gridDim.x, kWaveWorkers);
     for (uint32_t w = blockIdx.x; ; w += nwaves) {
         uint32_t i;
-        if (!sl_locate(wl.work, pre, w, i)) break;
+        if (!sl_locate(list, pre, w, i)) break;
         const float x = a.in.x[i], y = a.in.y[i], z = a.in.z[i];
         const float px = xf_row(a.X.m + 0, x, y, z, 1.0f), py = xf_row(a.X.m + 4, x, y, z, 1.0f), pz = xf_row(a.X.m + 8, x, y, z, 1.0f);
         // wave-uniform best: key = (d2 bits << 32 | row), plus the sorted position of that row
@@ -1065,7 +1078,7 @@ __global__ __launch_bounds__(256) void k_final_reduce(const double *__restrict__
             }
             __syncthreads();
             if (!(keep_nonempty && s_len > 0u))
-                for (int c = t; c < kShards; c += 256) counters_to_clear[c * kShardStride] = 0;
+                for (int c = t; c < 2 * kShards; c += 256) counters_to_clear[c * kShardStride] = 0;      // work list and retry list
         }
         if (t == 0) {
             *ticket = 0;
@@ -1210,7 +1223,15 @@ void launch_pass_tree_split(const PassArgs &a_in, const TargetIndex &ix, const W
         // first pass of an alignment: no query has a bound yet, which the wave-per-query walk needs (its frontier would
         // overflow and fall back to one lane): one thread per query whatever the list length (matters for shares or
         // clouds below the threshold, e.g. 1M points over 8 ranks)
-        hipLaunchKernelGGL(k_search_walk, dim3(walk_blocks), dim3(kWalkThreads), 0, s, a, ix, wl, a.pos_prev ? wave_mode_max : 0u);
+        const uint32_t wmm = a.pos_prev ? wave_mode_max : 0u;
+        if (a.budget_walk) {
+            static const uint32_t budget = getenv("SYMMICP_WALK_BUDGET") ? (uint32_t)atol(getenv("SYMMICP_WALK_BUDGET")) : 160u;
+            hipLaunchKernelGGL(k_search_walk<true>, dim3(walk_blocks), dim3(kWalkThreads), 0, s, a, ix, wl, wl.work, wmm, budget);
+            // the retry list: wave regime forced (every entry carries a bound now), no budget
+            hipLaunchKernelGGL(k_search_walk<false>, dim3(8192), dim3(kWalkThreads), 0, s, a, ix, wl, wl.retry, 0xFFFFFFFFu, 0xFFFFFFFFu);
+        } else {
+            hipLaunchKernelGGL(k_search_walk<false>, dim3(walk_blocks), dim3(kWalkThreads), 0, s, a, ix, wl, wl.work, wmm, 0xFFFFFFFFu);
+        }
     }
     if (ev) hipEventRecord(ev[3], s);
     hipLaunchKernelGGL(k_accumulate, dim3(acc_blocks), dim3(kPassThreads), 0, s, a, ix.tn);

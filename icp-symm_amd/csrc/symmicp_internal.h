@@ -77,8 +77,9 @@ struct ShardList {
     uint32_t cap;
 };
 struct WorkLists {
-    ShardList work;                       // queries k_search_cells hands to k_search_walk; counters cleared by the final reduce
-};
+    ShardList work;                       // queries k_search_cells hands to k_search_walk
+    ShardList retry;                      // queries the budgeted thread-per-query walk gave up on
+};                                        // the two counter blocks are contiguous and cleared by the final reduce
 
 struct PassArgs {
     // source share (planar).  `in` is read; if writeback, `out` receives the transformed points/normals
@@ -100,6 +101,7 @@ struct PassArgs {
     // pair certificates (TREE): position of the query when its pair was last searched, and the radius around it known
     // to hold no other target point (see k_search_cells)
     float4 *pairrec;                    // TREE: per pair, its own copy of the target's (point, normal) record (2 float4)
+    int32_t budget_walk;                // this pass's thread-per-query walk runs with a visit budget + retry launch (see k_search_walk)
     int32_t refresh_records;            // k_accumulate may replace stale copies (0 in a pass that may still be repaired)
     float4 *cert;                       // per pair: (ref.xyz, clear radius L around ref; L = 0: no certificate)
     int32_t use_slack;                  // 0 on the first pass of an alignment (certificates not valid yet)
