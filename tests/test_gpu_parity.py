@@ -676,7 +676,8 @@ def test_forced_repair_path_in_a_subprocess(sym):
     """SYMMICP_OPTIMISTIC=1 makes every pass skip the tree walk and repair itself afterwards if a query needed it (the
     switch is read once per process, hence the child process): the multi-pass exactness tests must still hold."""
     import subprocess
-    env = dict(os.environ, SYMMICP_OPTIMISTIC="1")
+    # (SYMMICP_BUDGET_WALK=1 as well: every first pass then runs the budgeted walk + retry launch of the sharded runs)
+    env = dict(os.environ, SYMMICP_OPTIMISTIC="1", SYMMICP_BUDGET_WALK="1")
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
                         "-k", "tree_follows_previous_pairs or randomised_exactness or pair_certificates or partial_overlap or sharded_ranks"],
                        env=env, capture_output=True, text=True, timeout=900)
