@@ -96,9 +96,28 @@ def main():
         dist.broadcast_object_list(job, src=0)
         eng.comm_init_shm(world, rank, job[0])
     elif world > 1:
-        uid = [symmicp.comm_get_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(uid, src=0)
-        eng.comm_init_rank(world, rank, uid[0])
+        # the library's own RCCL communicator (the unique id travels over torch.distributed).  Should RCCL refuse on any
+        # rank, every rank falls back to the shared-memory exchange (one node) instead of failing the run; the JSON
+        # line says which exchange was used.
+        ok = 1
+        try:
+            uid = [symmicp.comm_get_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(uid, src=0)
+            eng.comm_init_rank(world, rank, uid[0])
+        except symmicp.SymmIcpError as ex:
+            ok = 0
+            print("[bench] rank %d: RCCL communicator failed (%s)" % (rank, ex), file=sys.stderr)
+        t = torch.tensor([ok], dtype=torch.int32, device="cuda" if args.dist_backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        if int(t.item()) == 0:
+            if ok:      # this rank holds a communicator the others could not join: start over without it
+                eng.close()
+                eng = symmicp.Engine(device=local_rank, mode=getattr(symmicp, "MODE_" + args.mode.upper()),
+                                     corr=getattr(symmicp, "CORR_" + args.corr.upper()), max_iters=K, fixed_iters=1)
+            args.exchange = "shm"
+            job = ["%s_%d" % (os.environ.get("MASTER_PORT", "0"), os.getpid()) if rank == 0 else None]
+            dist.broadcast_object_list(job, src=0)
+            eng.comm_init_shm(world, rank, job[0])
     elif os.environ.get("SYMMICP_FORCE_COMM"):
         # rehearsal of the multi-GPU data path on one GPU: a real 1-rank RCCL communicator (all-reduce + publish per pass)
         eng.comm_init_rank(1, 0, symmicp.comm_get_unique_id())
