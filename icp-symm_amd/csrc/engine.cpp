@@ -647,7 +647,8 @@ int symmicp_set_target(symmicp_ctx *c, const float *xyz, size_t xr, size_t xc, c
     if (c->cfg.corr == SYMMICP_CORR_IDENTITY) return SYMMICP_OK;
 
     const double t1 = now_s();
-    HIP_TRY(c, keep_alloc(c, (void **)&c->tq, sizeof(float4) * n));
+    HIP_TRY(c, keep_alloc(c, (void **)&c->tq, sizeof(float4) * (n + 8)));     // + 8: the packet search reads a leaf's points in groups of 8
+    HIP_TRY(c, hipMemsetAsync(c->tq + n, 0, sizeof(float4) * 8, c->stream));
     HIP_TRY(c, keep_alloc(c, (void **)&c->tn, sizeof(float4) * 2 * n));      // (point, normal) pair records
     if (c->cfg.corr == SYMMICP_CORR_BRUTE) {
         launch_iota_f4(c->tgt.x, c->tgt.y, c->tgt.z, c->tgt.nx, c->tgt.ny, c->tgt.nz, c->n_t, c->tq, c->tn, c->stream);
@@ -894,6 +895,9 @@ static int run_pass(symmicp_ctx *c, const float Xapply[16], bool from_cur, bool 
             optimistic = opt_env ? (opt_env[0] == '1') : (!first && c->last_list_len == 0);
             if (writeback) optimistic = false;      // in-place write-back: a repair would transform the cloud twice
             // per-kernel events only in timing mode 2; mode 1 brackets the pass (events 0 and 4)
+            static const char *fp_env = std::getenv("SYMMICP_FIRST_PASS");          // "walk": the per-thread octree walk (A/B)
+            if (first && !(fp_env && fp_env[0] == 'w')) launch_pass_tree_first(a, c->ix, c->wl, ab, c->stream, c->timing == 2 ? ev : nullptr);
+            else
             launch_pass_tree_split(a, c->ix, c->wl, ab, walk_blocks, optimistic ? 1 : 0, c->stream, c->timing == 2 ? ev : nullptr);
             if (ev && c->timing == 2) c->ev_split[c->ev_used] = 2;
         }

@@ -991,6 +991,222 @@ __global__ __launch_bounds__(kWalkThreads, 6) void k_search_walk(PassArgs a, Tar
     }
 }
 
+// ---------------------------------------------------------------------------
+// k_search_packet: exact nearest neighbours for 64 queries at a time (one wave = one PACKET of 64 consecutive
+// queries of the Morton-sorted source, i.e. a compact patch of the cloud).
+//
+// The per-thread walk above pays for every node visit with 64 lanes' worth of divergent 16-byte loads and ~350
+// vector instructions, and a wave is as slow as its slowest lane.  Here the TRAVERSAL is wave-uniform (one stack in LDS,
+// scalar control flow) and only the distance tests are per lane:
+//   pop a node (its 32-byte record travels on the stack, so a pop needs no global load)
+//     every lane tests the node's box against its own query and bound; no lane wants it -> next pop
+//   leaf:     the leaf's points are wave-uniform loads; each lane tests each point (14 VALU per point for 64 queries)
+//   internal: lanes 0..7 load the <= 8 child records (one coalesced 256-byte read), test them against the packet's
+//             bounding box and the loosest bound of any lane, and push the survivors -- nearest on top (the order of
+//             the others does not matter: measured in scratch/sim_packet.py, sorted vs nearest-on-top: +2 % visits)
+// A node is expanded iff at least one lane needs it, so the packet visits the UNION of its lanes' node sets, but a
+// visit costs one wave-wide instruction stream instead of 64 divergent ones.  Exactness: a box is skipped only when
+// boxdist2 (same monotone fp32 expression as dist2) exceeds the lane's bound for every lane; ties resolve to the lowest
+// original row through the (d2, row) comparison, as in brute force.
+// `pad` > 0: scan everything within (nearest + pad), so that the result carries a pair certificate (see k_search_cells).
+// ---------------------------------------------------------------------------
+constexpr int kPktStack = 128;            // >= 7 * octree levels + 1
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_mov_f32(float x)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(x), __float_as_int(x), CTRL, ROW_MASK, 0xf, false));
+}
+
+// wave-wide max / min on the DPP network; every lane must be active.  Result is uniform (read from lane 63).
+__device__ __forceinline__ float wave_max_dpp(float x)
+{
+    x = fmaxf(x, dpp_mov_f32<0x111, 0xf>(x));
+    x = fmaxf(x, dpp_mov_f32<0x112, 0xf>(x));
+    x = fmaxf(x, dpp_mov_f32<0x114, 0xf>(x));
+    x = fmaxf(x, dpp_mov_f32<0x118, 0xf>(x));
+    x = fmaxf(x, dpp_mov_f32<0x142, 0xa>(x));
+    x = fmaxf(x, dpp_mov_f32<0x143, 0xc>(x));
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 63));
+}
+
+__device__ __forceinline__ float wave_min_dpp(float x)
+{
+    x = fminf(x, dpp_mov_f32<0x111, 0xf>(x));
+    x = fminf(x, dpp_mov_f32<0x112, 0xf>(x));
+    x = fminf(x, dpp_mov_f32<0x114, 0xf>(x));
+    x = fminf(x, dpp_mov_f32<0x118, 0xf>(x));
+    x = fminf(x, dpp_mov_f32<0x142, 0xa>(x));
+    x = fminf(x, dpp_mov_f32<0x143, 0xc>(x));
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 63));
+}
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// two 64-byte scalar loads from a wave-uniform address (hipcc does not count asm loads: the wait is part of the statement)
+__device__ __forceinline__ void sload_2x16(const void *p, f32x16 &a, f32x16 &b)
+{
+    asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx16 %1, %2, 0x40\n\ts_waitcnt lgkmcnt(0)" : "=&s"(a), "=&s"(b) : "s"(p) : "memory");
+}
+
+struct PktBest {
+    float d2, second;
+    int32_t row, pos;
+};
+
+__device__ __forceinline__ void pkt_test_point(PktBest &b, float px, float py, float pz, float qx, float qy, float qz, int32_t row, int32_t pos)
+{
+    const float d2 = dist2(px, py, pz, qx, qy, qz);
+    const bool better = (d2 < b.d2) | ((d2 == b.d2) & (row < b.row));
+    b.second = fminf(b.second, fmaxf(d2, b.d2));       // the loser of every comparison is a candidate for second-nearest
+    b.d2 = better ? d2 : b.d2;
+    b.row = better ? row : b.row;
+    b.pos = better ? pos : b.pos;
+}
+
+__device__ __forceinline__ float pkt_threshold(float d2, float pad)
+{
+    if (pad <= 0.0f) return d2;
+    const float rp = __builtin_amdgcn_sqrtf(d2) * 1.00001f + pad;
+    return rp * rp * 1.00001f;
+}
+
+// FROM_LIST = false: the packets are the queries [0, n) in order (first pass of an alignment: no previous pairs).
+// FROM_LIST = true:  the packets are consecutive entries of `list` (queries another kernel could not settle); the
+//                    previous pair's current distance (d2_out[i], provisional pos_out[i]) bounds each lane's search.
+template <bool FROM_LIST>
+__global__ __launch_bounds__(64, 8) void k_search_packet(PassArgs a, TargetIndex ix, ShardList list, float pad)
+{
+    __shared__ float4 stk[kPktStack][2];
+    __shared__ uint32_t s_off[kMortonBits + 2];
+    __shared__ uint32_t pre[kShards + 1];
+    const int lane = threadIdx.x;
+    const float inf = __int_as_float(0x7f800000);
+    if (lane < kMortonBits + 2) s_off[lane] = ix.olevel_off[lane];
+    uint32_t npk;
+    if (FROM_LIST) { sl_prefix(list, pre); npk = (pre[kShards] + 63u) >> 6; }
+    else { __syncthreads(); npk = (a.n + 63u) >> 6; }
+    const float4 *__restrict__ tq = ix.tq;
+    const float4 *__restrict__ onodes = ix.onodes;
+    unsigned long long c_int = 0, c_leaf = 0, c_rej = 0, c_pts = 0;
+    for (uint32_t pk = FROM_LIST ? blockIdx.x : xcd_remap(blockIdx.x, gridDim.x); pk < npk; pk += gridDim.x) {
+        uint32_t i = pk * 64u + (uint32_t)lane;
+        bool active;
+        if (FROM_LIST) active = sl_locate(list, pre, i, i);
+        else active = i < a.n;
+        float px = 0.f, py = 0.f, pz = 0.f;
+        PktBest b;
+        b.d2 = inf; b.second = inf; b.row = 0x7fffffff; b.pos = -1;
+        float thr = -1.0f;                 // prune bound on d2; -1: this lane wants nothing
+        if (active) {
+            const float x = a.in.x[i], y = a.in.y[i], z = a.in.z[i];
+            px = xf_row(a.X.m + 0, x, y, z, 1.0f); py = xf_row(a.X.m + 4, x, y, z, 1.0f); pz = xf_row(a.X.m + 8, x, y, z, 1.0f);
+            thr = inf;
+            if (FROM_LIST) {
+                // the provisional pair only bounds the search: its point is met again in the scan and wins (or ties) there
+                const float d0 = a.d2_out[i];
+                if (a.pos_out[i] >= 0 && d0 < inf) thr = pkt_threshold(d0, pad);
+            }
+            if (!((px == px) & (py == py) & (pz == pz))) { thr = -1.0f; }      // NaN query: no pair
+        }
+        // the packet's bounding box (lanes that want nothing do not stretch it)
+        const bool wants = thr >= 0.0f;
+        const float qlx = wave_min_dpp(wants ? px : inf), qly = wave_min_dpp(wants ? py : inf), qlz = wave_min_dpp(wants ? pz : inf);
+        const float qhx = wave_max_dpp(wants ? px : -inf), qhy = wave_max_dpp(wants ? py : -inf), qhz = wave_max_dpp(wants ? pz : -inf);
+        float thr_max = wave_max_dpp(thr);
+        int sp = 0;
+        if (thr_max >= 0.0f) {
+            if (lane == 0) {
+                float4 rA = onodes[0], rB = onodes[1];
+                stk[0][0] = rA; stk[0][1] = rB;           // level 0 in bits 28..31 of the packed word: already 0
+            }
+            sp = 1;
+        }
+        __builtin_amdgcn_wave_barrier();
+        while (sp > 0) {
+            sp--;
+            const float4 nA = stk[sp][0], nB = stk[sp][1];
+            const bool want = boxdist2(px, py, pz, nA, nB) <= thr;
+            if (__ballot(want) == 0ull) { c_rej++; continue; }
+            const uint32_t first = (uint32_t)__builtin_amdgcn_readfirstlane(__float_as_int(nA.w));
+            const uint32_t packed = (uint32_t)__builtin_amdgcn_readfirstlane(__float_as_int(nB.w));
+            const uint32_t level = packed >> 28, nch = (packed >> 24) & 15u, cf = packed & 0xFFFFFFu;
+            if (nch == 0) {
+                // leaf: cf points starting at tq[first]; wave-uniform loads, 8 at a time
+                c_leaf++; c_pts += cf;
+                for (uint32_t e0 = 0; e0 < cf; e0 += 8) {
+                    const uint32_t m = min(cf - e0, 8u);
+                    // 8 points = 128 bytes through the scalar cache (tq is padded by 8 entries); operands of the
+                    // distance tests are then SGPRs: no broadcast, no vector-memory traffic
+                    f32x16 qa, qb;
+                    sload_2x16(tq + first + e0, qa, qb);
+#pragma unroll
+                    for (int k = 0; k < 4; k++)
+                        if ((uint32_t)k < m) pkt_test_point(b, px, py, pz, qa[4 * k], qa[4 * k + 1], qa[4 * k + 2], __float_as_int(qa[4 * k + 3]), (int32_t)(first + e0 + k));
+#pragma unroll
+                    for (int k = 0; k < 4; k++)
+                        if ((uint32_t)(k + 4) < m) pkt_test_point(b, px, py, pz, qb[4 * k], qb[4 * k + 1], qb[4 * k + 2], __float_as_int(qb[4 * k + 3]), (int32_t)(first + e0 + 4 + k));
+                }
+                thr = fminf(thr, pkt_threshold(b.d2, pad));
+                thr_max = wave_max_dpp(thr);
+            } else {
+                c_int++;
+                float bbd = inf;
+                float4 cA = make_float4(0.f, 0.f, 0.f, 0.f), cB = cA;
+                const bool mine = (uint32_t)lane < nch;
+                if (mine) {
+                    const float4 *__restrict__ ch = onodes + 2 * ((size_t)s_off[level + 1] + cf + (uint32_t)lane);
+                    cA = ch[0]; cB = ch[1];
+                    // distance between the child's box and the packet's box (lower bound for every lane)
+                    const float gx = fmaxf(fmaxf(cA.x - qhx, qlx - cB.x), 0.0f);
+                    const float gy = fmaxf(fmaxf(cA.y - qhy, qly - cB.y), 0.0f);
+                    const float gz = fmaxf(fmaxf(cA.z - qhz, qlz - cB.z), 0.0f);
+                    bbd = (gx * gx + gy * gy) + gz * gz;
+                }
+                const bool keep = mine && bbd <= thr_max;
+                const uint32_t mask = (uint32_t)__ballot(keep);
+                if (mask) {
+                    // nearest survivor on top of the stack, the others below it in lane order
+                    const uint32_t key = keep ? ((__float_as_uint(bbd) & ~7u) | (uint32_t)lane) : 0xFFFFFFFFu;
+                    uint32_t kmin = key;
+                    kmin = min(kmin, (uint32_t)__builtin_amdgcn_update_dpp((int)kmin, (int)kmin, 0x111, 0xf, 0xf, false));   // row_shr:1
+                    kmin = min(kmin, (uint32_t)__builtin_amdgcn_update_dpp((int)kmin, (int)kmin, 0x112, 0xf, 0xf, false));   // row_shr:2
+                    kmin = min(kmin, (uint32_t)__builtin_amdgcn_update_dpp((int)kmin, (int)kmin, 0x114, 0xf, 0xf, false));   // row_shr:4 -> lane 7 holds min of lanes 0..7
+                    const uint32_t cmin = (uint32_t)__builtin_amdgcn_readlane((int)kmin, 7) & 7u;
+                    const uint32_t nk = (uint32_t)__popc(mask);
+                    const uint32_t rank = (uint32_t)__popc(mask & ((1u << (lane & 7)) - 1u));
+                    const uint32_t rmin = (uint32_t)__popc(mask & ((1u << cmin) - 1u));
+                    if (keep) {
+                        const uint32_t slot = ((uint32_t)lane == cmin) ? nk - 1u : (rank > rmin ? rank - 1u : rank);
+                        cB.w = __int_as_float((int)(((uint32_t)__float_as_int(cB.w) & 0x0FFFFFFFu) | ((level + 1u) << 28)));
+                        stk[sp + slot][0] = cA; stk[sp + slot][1] = cB;
+                    }
+                    sp += (int)nk;
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        if (active) {
+            a.pos_out[i] = b.pos;
+            a.d2_out[i] = b.d2;
+            float L = 0.0f;
+            if (pad > 0.0f && b.pos >= 0) {
+                const float d1 = sqrtf(b.d2);
+                const float Lc = fminf(sqrtf(b.second) * 0.999999f, (d1 + pad) * 0.99999f);
+                L = (Lc > d1 * 1.000001f) ? Lc : 0.0f;
+            }
+            a.cert[i] = make_float4(px, py, pz, L);
+            if (b.pos >= 0) store_pair_record(a, ix, i, b.pos);
+            else a.pairrec[2 * (size_t)i + 1] = make_float4(0.f, 0.f, 0.f, 1.f);
+        }
+    }
+    if (ix.dbg && lane == 0) {
+        atomicAdd(ix.dbg + 4, c_int + c_leaf);
+        atomicAdd(ix.dbg + 5, c_rej);
+        atomicAdd(ix.dbg + 3, c_pts);
+    }
+}
+
 // The pair's distance is recomputed from the gathered q (bit-identical to the stored one) instead of being read.
 // (A 4-points-per-thread variant with 16-byte column loads was measured and is no faster: the two 16-byte gathers per
 // pair bound this kernel, not the column loads.  Few blocks are: each one ends in a 40-value block reduction.)
@@ -1233,6 +1449,20 @@ void launch_pass_tree_split(const PassArgs &a_in, const TargetIndex &ix, const W
             hipLaunchKernelGGL(k_search_walk<false>, dim3(walk_blocks), dim3(kWalkThreads), 0, s, a, ix, wl, wl.work, wmm, 0xFFFFFFFFu);
         }
     }
+    if (ev) hipEventRecord(ev[3], s);
+    hipLaunchKernelGGL(k_accumulate, dim3(acc_blocks), dim3(kPassThreads), 0, s, a, ix.tn);
+    if (ev) hipEventRecord(ev[4], s);
+}
+
+// first pass of an alignment: no previous pairs, every query is searched -- packets over the whole (sorted) share
+void launch_pass_tree_first(const PassArgs &a_in, const TargetIndex &ix, const WorkLists &wl, int acc_blocks, hipStream_t s, hipEvent_t *ev)
+{
+    PassArgs a = a_in;
+    a.refresh_records = 1;
+    const uint32_t npk = (a.n + 63u) / 64u;
+    const uint32_t nbp = ((npk + 7u) / 8u) * 8u;
+    if (ev) { hipEventRecord(ev[0], s); hipEventRecord(ev[1], s); hipEventRecord(ev[2], s); }
+    hipLaunchKernelGGL(k_search_packet<false>, dim3(nbp), dim3(64), 0, s, a, ix, wl.work, 0.0f);
     if (ev) hipEventRecord(ev[3], s);
     hipLaunchKernelGGL(k_accumulate, dim3(acc_blocks), dim3(kPassThreads), 0, s, a, ix.tn);
     if (ev) hipEventRecord(ev[4], s);

@@ -115,6 +115,7 @@ void launch_pass_indexed(const PassArgs &a, const float4 *tn /* pair records */,
 // stage: 0 = cells, walk, accumulate; 1 = cells, accumulate (walk skipped); 2 = walk, accumulate (repair of a stage-1 pass)
 void launch_pass_tree_split(const PassArgs &a, const TargetIndex &ix, const WorkLists &wl, int acc_blocks, uint32_t walk_blocks,
                             int stage, hipStream_t s, hipEvent_t *ev);
+void launch_pass_tree_first(const PassArgs &a, const TargetIndex &ix, const WorkLists &wl, int acc_blocks, hipStream_t s, hipEvent_t *ev);
 uint32_t walk_blocks_full(const WorkLists &wl);
 uint32_t shard_capacity(uint32_t n_points);
 // keep_nonempty: leave the append-list counters alone when the work list is not empty (stage-1 passes)
