@@ -460,10 +460,9 @@ void launch_oct_first(const uint32_t *keys, uint32_t n, int level, const uint32_
 }
 
 void launch_oct_nodes(int level, const float4 *tq, uint32_t n, const uint32_t *first, uint32_t n_nodes, const uint32_t *nid_next,
-                      uint32_t n_nodes_next, const float4 *nodes_next, float4 *nodes, hipStream_t s)
+                      uint32_t n_nodes_next, const float4 *nodes_next, float4 *nodes, uint32_t leaf_max, hipStream_t s)
 {
-    // a cell with at most this many points is a leaf (the walk tests 8 entities per trip)
-    static const uint32_t leaf_max = getenv("SYMMICP_OCT_LEAF") ? (uint32_t)atoi(getenv("SYMMICP_OCT_LEAF")) : 8u;
+    // leaf_max: a cell with at most this many points is a leaf
     hipLaunchKernelGGL(k_oct_nodes, dim3((n_nodes + 255) / 256), dim3(256), 0, s, level, tq, n, first, n_nodes, nid_next, n_nodes_next,
                        nodes_next, nodes, leaf_max);
 }

@@ -1,0 +1,527 @@
+// kernels_packet.hip -- exact nearest neighbours for 64 queries at a time (gfx950).
+//
+// Fills the correspondence step the reference leaves as a todo (ICP/myicp.cpp:128-131) for the passes in which most
+// queries have to be searched (the first pass of an alignment, the passes right after a large motion).
+//
+// One wave = one PACKET of 64 consecutive queries of the Morton-sorted source, i.e. a compact patch of the cloud.  A
+// per-thread tree walk pays for every node visit with 64 lanes' worth of divergent 16-byte loads and a few hundred vector
+// instructions, and a wave is as slow as its slowest lane; a depth-first traversal shared by the wave (the first form of
+// this kernel, kept below as the overflow fallback) cuts the instructions but is one chain of ~300 dependent LDS and
+// memory round trips per packet: 1.1 ms for the first pass of the 1M-point surface pair against 1.7 ms for the
+// per-thread walk, latency-bound (occupancy 32 -> 16 -> 8 waves per CU: 1.08 -> 1.28 -> 1.60 ms) with a tail of packets
+// whose queries sit in several clusters (up to 2300 pops against a mean of 215).  So the traversal is BREADTH-first:
+//   dive      root to leaf along the children nearest to a query in the middle of the packet (no siblings kept); every
+//             lane tests that leaf's points: all 64 queries now have a finite bound (~11 dependent loads)
+//   levels    the frontier of a level sits in LDS; 8 frontier nodes x 8 child slots are handled per step, ONE LANE PER
+//             CHILD: the lane loads the child's 32-byte record (all loads of a step are independent) and tests its box
+//             against the bounding boxes and loosest bounds of the packet's four 16-query sub-groups (wave-uniform SGPR
+//             operands).  Surviving internal nodes are compacted into the next frontier (ballot + mbcnt)
+//   leaves    a surviving leaf's lane also loads the leaf's points (up to 8, 16 bytes each) into its own registers: all
+//             leaves of a step load at once.  Leaves are then taken one at a time: box and points are broadcast with
+//             v_readlane (SGPR operands), every lane tests the box against its own bound (no lane needs it -> skip), then
+//             the points: ~14 vector instructions per point for all 64 queries; bounds tighten as leaves are scanned
+// A packet is ~25 dependent round trips and ~12 k vector instructions instead of ~300 and ~21 k.
+//
+// Exactness.  A box is skipped only when boxdist2 (the same monotone fp32 expression as dist2, so boxdist2 <= dist2 to
+// every point inside) exceeds the lane's bound for every lane; the sub-group test is the same expression on interval
+// gaps (a lower bound of boxdist2 for every lane of the sub-group).  The running best of a lane is the lexicographic
+// minimum of (d2, original row) over the points seen so far, as in brute force: the fast path keeps the first point
+// that reaches a strictly smaller d2 and flags equal distances; a flagged group of points is scanned again with the row
+// comparison (rare).
+// CERT: scan everything within (nearest + pad) and keep the second-nearest distance, so that the result carries a pair
+// certificate (see k_search_cells in kernels_pass.hip).
+#include <cstdlib>
+#include "symmicp_internal.h"
+#include "device_common.h"
+#pragma clang fp contract(off)
+
+namespace symmicp {
+
+constexpr int kPktStack = 128;            // >= 7 * octree levels + 1
+static_assert(kPktStack >= 7 * (kMortonBits + 1) + 1, "packet stack too small for the octree depth");
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// two 64-byte scalar loads from a wave-uniform address (hipcc does not count asm loads: the wait is part of the statement)
+__device__ __forceinline__ void sload_2x16(const void *p, f32x16 &a, f32x16 &b)
+{
+    // (provably uniform for the compiler: inside a non-inlined function the pointer arrives in vector registers)
+    const unsigned long long u = (unsigned long long)p;
+    p = (const void *)(((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(u >> 32)) << 32) |
+                       (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)u));
+    asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx16 %1, %2, 0x40\n\ts_waitcnt lgkmcnt(0)" : "=&s"(a), "=&s"(b) : "s"(p) : "memory");
+}
+
+// ---- cross-lane reductions on the DPP network -------------------------------------------------------------
+// unsigned max / min: used on the bit patterns of non-negative floats (same order), identity as `old` so the
+// compiler can fold the move into the ALU instruction
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_umax(uint32_t x)
+{
+    return max(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, ROW_MASK, 0xf, false));
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_umin(uint32_t x)
+{
+    return min(x, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)x, CTRL, ROW_MASK, 0xf, false));
+}
+template <int CTRL>
+__device__ __forceinline__ float dpp_fmin(float x)
+{
+    return fminf(x, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(x), __float_as_int(x), CTRL, 0xf, 0xf, false)));
+}
+template <int CTRL>
+__device__ __forceinline__ float dpp_fmax(float x)
+{
+    return fmaxf(x, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(x), __float_as_int(x), CTRL, 0xf, 0xf, false)));
+}
+// reductions over the 16 lanes of a row; the result sits in the row's last lane (15, 31, 47, 63)
+__device__ __forceinline__ float row_fmin(float x)
+{
+    x = dpp_fmin<0x111>(x); x = dpp_fmin<0x112>(x); x = dpp_fmin<0x114>(x); x = dpp_fmin<0x118>(x);
+    return x;
+}
+__device__ __forceinline__ float row_fmax(float x)
+{
+    x = dpp_fmax<0x111>(x); x = dpp_fmax<0x112>(x); x = dpp_fmax<0x114>(x); x = dpp_fmax<0x118>(x);
+    return x;
+}
+__device__ __forceinline__ uint32_t row_umax(uint32_t x)
+{
+    x = dpp_umax<0x111, 0xf>(x); x = dpp_umax<0x112, 0xf>(x); x = dpp_umax<0x114, 0xf>(x); x = dpp_umax<0x118, 0xf>(x);
+    return x;
+}
+
+__device__ __forceinline__ float pkt_threshold(float d2, float pad)
+{
+    if (pad <= 0.0f) return d2;
+    const float rp = __builtin_amdgcn_sqrtf(d2) * 1.00001f + pad;
+    return rp * rp * 1.00001f;
+}
+
+struct PktBest {
+    float d2;           // nearest so far
+    uint32_t second;    // CERT: bits of the second-nearest d2 seen
+    int32_t pos;        // sorted position of the nearest
+};
+
+// fast path for one point: strict improvement only; equal distances are flagged in `tie`
+template <bool CERT, int K>
+__device__ __forceinline__ void pkt_point(PktBest &b, int32_t &slot, unsigned long long &tie, float px, float py, float pz, float qx, float qy, float qz)
+{
+    const float d2 = dist2(px, py, pz, qx, qy, qz);
+    const bool lt = d2 < b.d2;
+    tie |= __ballot(d2 == b.d2);
+    if (CERT) b.second = min(b.second, max(__float_as_uint(d2), __float_as_uint(b.d2)));      // the loser of every comparison
+    b.d2 = lt ? d2 : b.d2;
+    slot = lt ? K : slot;
+}
+
+// ---- scanning one leaf ------------------------------------------------------------------------------------------
+// Tie rule shared by both forms: after the fast path b.d2 is the minimum over everything seen; if some lane met a point
+// exactly as far as its best at that moment, the lowest original row among the points AT that distance has to win, so
+// the rows of this group's points at that distance are compared with the row of the current holder.
+
+// (first, cnt) wave-uniform; the points come through the scalar cache, 8 at a time (tq is padded by 8 entries)
+template <bool CERT>
+__device__ __forceinline__ void pkt_leaf_scalar(const float4 *__restrict__ tq, uint32_t first, uint32_t cnt, float px, float py, float pz,
+                                                PktBest &b, unsigned long long &c_tie)
+{
+    for (uint32_t e0 = 0; e0 < cnt; e0 += 8) {
+        const uint32_t m = min(cnt - e0, 8u);
+        f32x16 qa, qb;
+        sload_2x16(tq + first + e0, qa, qb);
+        int32_t slot = 8;
+        unsigned long long tie = 0;
+        pkt_point<CERT, 0>(b, slot, tie, px, py, pz, qa[0], qa[1], qa[2]);
+        if (m > 1u) pkt_point<CERT, 1>(b, slot, tie, px, py, pz, qa[4], qa[5], qa[6]);
+        if (m > 2u) pkt_point<CERT, 2>(b, slot, tie, px, py, pz, qa[8], qa[9], qa[10]);
+        if (m > 3u) pkt_point<CERT, 3>(b, slot, tie, px, py, pz, qa[12], qa[13], qa[14]);
+        if (m > 4u) pkt_point<CERT, 4>(b, slot, tie, px, py, pz, qb[0], qb[1], qb[2]);
+        if (m > 5u) pkt_point<CERT, 5>(b, slot, tie, px, py, pz, qb[4], qb[5], qb[6]);
+        if (m > 6u) pkt_point<CERT, 6>(b, slot, tie, px, py, pz, qb[8], qb[9], qb[10]);
+        if (m > 7u) pkt_point<CERT, 7>(b, slot, tie, px, py, pz, qb[12], qb[13], qb[14]);
+        if (slot != 8) b.pos = (int32_t)(first + e0) + slot;
+        if (tie != 0ull) {
+            c_tie++;
+            int32_t brow = (b.pos >= 0) ? __float_as_int(tq[b.pos].w) : 0x7fffffff;
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                if ((uint32_t)k < m) {
+                    const float qx = k < 4 ? qa[4 * k] : qb[4 * (k - 4)], qy = k < 4 ? qa[4 * k + 1] : qb[4 * (k - 4) + 1],
+                                qz = k < 4 ? qa[4 * k + 2] : qb[4 * (k - 4) + 2];
+                    const int32_t row = __float_as_int(k < 4 ? qa[4 * k + 3] : qb[4 * (k - 4) + 3]);
+                    const float d2 = dist2(px, py, pz, qx, qy, qz);
+                    if (d2 == b.d2 && row < brow) { brow = row; b.pos = (int32_t)(first + e0) + k; }
+                }
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ float bcast(float v, int src_lane)
+{
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src_lane));
+}
+
+// the first m (<= 8) points of the leaf sit in the registers pt[0..7] of lane `src` (wave-uniform): broadcast and test
+template <bool CERT>
+__device__ __forceinline__ void pkt_leaf_regs(const float4 *__restrict__ tq, const float4 (&pt)[8], int src, uint32_t first, uint32_t m, float px,
+                                              float py, float pz, PktBest &b, unsigned long long &c_tie)
+{
+    int32_t slot = 8;
+    unsigned long long tie = 0;
+    pkt_point<CERT, 0>(b, slot, tie, px, py, pz, bcast(pt[0].x, src), bcast(pt[0].y, src), bcast(pt[0].z, src));
+    if (m > 1u) pkt_point<CERT, 1>(b, slot, tie, px, py, pz, bcast(pt[1].x, src), bcast(pt[1].y, src), bcast(pt[1].z, src));
+    if (m > 2u) pkt_point<CERT, 2>(b, slot, tie, px, py, pz, bcast(pt[2].x, src), bcast(pt[2].y, src), bcast(pt[2].z, src));
+    if (m > 3u) pkt_point<CERT, 3>(b, slot, tie, px, py, pz, bcast(pt[3].x, src), bcast(pt[3].y, src), bcast(pt[3].z, src));
+    if (m > 4u) pkt_point<CERT, 4>(b, slot, tie, px, py, pz, bcast(pt[4].x, src), bcast(pt[4].y, src), bcast(pt[4].z, src));
+    if (m > 5u) pkt_point<CERT, 5>(b, slot, tie, px, py, pz, bcast(pt[5].x, src), bcast(pt[5].y, src), bcast(pt[5].z, src));
+    if (m > 6u) pkt_point<CERT, 6>(b, slot, tie, px, py, pz, bcast(pt[6].x, src), bcast(pt[6].y, src), bcast(pt[6].z, src));
+    if (m > 7u) pkt_point<CERT, 7>(b, slot, tie, px, py, pz, bcast(pt[7].x, src), bcast(pt[7].y, src), bcast(pt[7].z, src));
+    if (slot != 8) b.pos = (int32_t)first + slot;
+    if (tie != 0ull) {
+        c_tie++;
+        int32_t brow = (b.pos >= 0) ? __float_as_int(tq[b.pos].w) : 0x7fffffff;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            if ((uint32_t)k < m) {
+                const int32_t row = __builtin_amdgcn_readlane(__float_as_int(pt[k].w), src);
+                const float d2 = dist2(px, py, pz, bcast(pt[k].x, src), bcast(pt[k].y, src), bcast(pt[k].z, src));
+                if (d2 == b.d2 && row < brow) { brow = row; b.pos = (int32_t)first + k; }
+            }
+        }
+    }
+}
+
+// ---- depth-first traversal shared by the wave (fallback when a frontier outgrows its LDS slot) -------------------------
+// pop a node (its 32-byte record travels on the stack); every lane tests the node's box against its own bound; no lane
+// wants it -> next pop; leaf -> scan; internal -> lane 4c+g tests child c against sub-group g's box and bound, the
+// children some sub-group may need are pushed, the nearest on top.  Exact for any starting bounds.
+struct PktCounters {
+    unsigned long long nodes, leaves, rejected, points, ties, steps, overflow;
+};
+
+template <bool CERT>
+__device__ __noinline__ void pkt_dfs(const float4 *__restrict__ onodes, const float4 *__restrict__ tq, const uint32_t *s_off, float4 (*stk)[2],
+                                     const float (*s_sb)[8], float px, float py, float pz, PktBest &b, float &thr, float pad, PktCounters &cn)
+{
+    const int lane = threadIdx.x;
+    const int sub = lane & 3, chl = lane >> 2;                          // lane 4c+g = (child c, sub-group g)
+    const int bperm = (16 * sub + 15) * 4;                              // ds_bpermute address of sub-group g's last lane
+    const float4 sblo = *reinterpret_cast<const float4 *>(&s_sb[sub][0]), sbhi = *reinterpret_cast<const float4 *>(&s_sb[sub][4]);
+    if (lane == 0) {
+        const float4 rA = onodes[0], rB = onodes[1];
+        stk[0][0] = rA; stk[0][1] = rB;                                 // level 0 in bits 28..31 of the packed word: already 0
+    }
+    int sp = 1;
+    __builtin_amdgcn_wave_barrier();
+    while (sp > 0) {
+        sp--;
+        const float4 nA = stk[sp][0], nB = stk[sp][1];
+        const bool want = boxdist2(px, py, pz, nA, nB) <= thr;
+        if (__ballot(want) == 0ull) { cn.rejected++; continue; }
+        const uint32_t first = (uint32_t)__builtin_amdgcn_readfirstlane(__float_as_int(nA.w));
+        const uint32_t packed = (uint32_t)__builtin_amdgcn_readfirstlane(__float_as_int(nB.w));
+        const uint32_t level = packed >> 28, nch = (packed >> 24) & 15u, cf = packed & 0xFFFFFFu;
+        if (nch == 0) {
+            cn.leaves++; cn.points += cf;
+            pkt_leaf_scalar<CERT>(tq, first, cf, px, py, pz, b, cn.ties);
+            thr = fminf(thr, pkt_threshold(b.d2, pad));
+        } else {
+            cn.nodes++;
+            const uint32_t tb = (thr >= 0.0f) ? __float_as_uint(thr) + 1u : 0u;      // 0: the lane wants nothing; else bits + 1 (a bound of 0 still admits gap 0)
+            const uint32_t thr_g = (uint32_t)__builtin_amdgcn_ds_bpermute(bperm, (int)row_umax(tb));
+            uint32_t bbd = 0x7f800000u;
+            float4 cA = make_float4(0.f, 0.f, 0.f, 0.f), cB = cA;
+            const bool mine = (lane < 32) && ((uint32_t)chl < nch);
+            if (mine) {
+                const float4 *__restrict__ ch = onodes + 2 * ((size_t)s_off[level + 1] + cf + (uint32_t)chl);
+                cA = ch[0]; cB = ch[1];
+                const float gx = fmaxf(fmaxf(cA.x - sbhi.x, sblo.x - cB.x), 0.0f);
+                const float gy = fmaxf(fmaxf(cA.y - sbhi.y, sblo.y - cB.y), 0.0f);
+                const float gz = fmaxf(fmaxf(cA.z - sbhi.z, sblo.z - cB.z), 0.0f);
+                bbd = __float_as_uint((gx * gx + gy * gy) + gz * gz);
+            }
+            const bool keep = mine && bbd < thr_g;
+            const uint32_t m32 = (uint32_t)__ballot(keep);
+            if (m32) {
+                uint32_t mc = m32 | (m32 >> 1);
+                mc = (mc | (mc >> 2)) & 0x11111111u;                     // bit 4c: child c is needed by some sub-group
+                uint32_t key = keep ? ((bbd & ~7u) | (uint32_t)chl) : 0xFFFFFFFFu;
+                key = dpp_umin<0xB1, 0xf>(key);                          // quad_perm [1,0,3,2]
+                key = dpp_umin<0x4E, 0xf>(key);                          // quad_perm [2,3,0,1]: every lane of the quad holds the child's minimum
+                key = dpp_umin<0x114, 0xf>(key);                         // row_shr:4
+                key = dpp_umin<0x118, 0xf>(key);                         // row_shr:8: lanes 15 / 31 hold children 0..3 / 4..7
+                const uint32_t kmin = min((uint32_t)__builtin_amdgcn_readlane((int)key, 15), (uint32_t)__builtin_amdgcn_readlane((int)key, 31));
+                const uint32_t cmin = kmin & 7u;
+                const uint32_t nk = (uint32_t)__popc(mc);
+                const uint32_t rank = (uint32_t)__popc(mc & ((1u << (4 * (chl & 7))) - 1u));
+                const uint32_t rmin = (uint32_t)__popc(mc & ((1u << (4 * cmin)) - 1u));
+                if (mine && sub == 0 && ((mc >> (4 * (chl & 7))) & 1u)) {
+                    const uint32_t slot = ((uint32_t)chl == cmin) ? nk - 1u : (rank > rmin ? rank - 1u : rank);
+                    cB.w = __int_as_float((int)(((uint32_t)__float_as_int(cB.w) & 0x0FFFFFFFu) | ((level + 1u) << 28)));
+                    stk[sp + slot][0] = cA; stk[sp + slot][1] = cB;
+                }
+                sp += (int)nk;
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+}
+
+// Where the packets come from:
+//   PKT_ALL   the queries [0, n) in order, 64 per packet (first pass of an alignment: no previous pairs)
+//   PKT_LIST  consecutive entries of `list`, 64 per packet (queries another kernel could not settle); the current distance
+//             to the previous pair's point (d2_out[i], with pos_out[i] >= 0) bounds each lane
+enum { PKT_ALL = 0, PKT_LIST = 1 };
+constexpr int kFrontCap = 512;            // frontier nodes per level (two buffers of uint32 in LDS = the DFS stack's 4 KB)
+static_assert(2 * kFrontCap * sizeof(uint32_t) == kPktStack * 2 * sizeof(float4), "frontier buffers alias the DFS stack");
+
+#ifndef PKT_WAVES
+#define PKT_WAVES 4
+#endif
+template <int SRC, bool CERT, bool DBG>
+__global__ __launch_bounds__(64, PKT_WAVES) void k_search_packet(PassArgs a, TargetIndex ix, ShardList list, float pad)
+{
+    __shared__ float4 s_buf[kPktStack][2];         // BFS: two frontier buffers; DFS fallback: the stack
+    __shared__ float s_sb[4][8];                   // bounding boxes of the four 16-query sub-groups
+    __shared__ uint32_t s_off[kMortonBits + 2];
+    __shared__ uint32_t pre[kShards + 1];
+    uint32_t (*fr)[kFrontCap] = reinterpret_cast<uint32_t (*)[kFrontCap]>(&s_buf[0][0]);
+    const int lane = threadIdx.x;
+    const float inf = __int_as_float(0x7f800000);
+    if (lane < kMortonBits + 2) s_off[lane] = ix.olevel_off[lane];
+    uint32_t npk;
+    if (SRC == PKT_LIST) { sl_prefix(list, pre); npk = (pre[kShards] + 63u) >> 6; }
+    else { __syncthreads(); npk = (a.n + 63u) >> 6; }
+    const float4 *__restrict__ tq = ix.tq;
+    const float4 *__restrict__ onodes = ix.onodes;
+    PktCounters cn = {0, 0, 0, 0, 0, 0, 0};
+    for (uint32_t pk = (SRC == PKT_LIST) ? blockIdx.x : xcd_remap(blockIdx.x, gridDim.x); pk < npk; pk += gridDim.x) {
+        unsigned long long t_start = 0;
+        if (DBG) t_start = __builtin_amdgcn_s_memrealtime();
+        uint32_t i = pk * 64u + (uint32_t)lane;
+        bool active;
+        if (SRC == PKT_LIST) active = sl_locate(list, pre, i, i);
+        else active = i < a.n;
+        float px = 0.f, py = 0.f, pz = 0.f;
+        PktBest b;
+        b.d2 = inf; b.second = 0x7f800000u; b.pos = -1;
+        float thr = -1.0f;                 // prune bound on d2; -1: this lane wants nothing
+        if (active) {
+            const float x = a.in.x[i], y = a.in.y[i], z = a.in.z[i];
+            px = xf_row(a.X.m + 0, x, y, z, 1.0f); py = xf_row(a.X.m + 4, x, y, z, 1.0f); pz = xf_row(a.X.m + 8, x, y, z, 1.0f);
+            thr = inf;
+            if (SRC == PKT_LIST) {
+                // the provisional pair only bounds the search: its point is met again in the scan and wins (or ties) there
+                const float d0 = a.d2_out[i];
+                if (a.pos_out[i] >= 0 && d0 < inf) thr = pkt_threshold(d0, pad);
+            }
+            if (!((px == px) & (py == py) & (pz == pz))) thr = -1.0f;      // NaN query: no pair
+        }
+        const unsigned long long wants0 = __ballot(thr >= 0.0f);
+        uint32_t steps_pk = 0;
+        bool ovf_pk = false;
+        if (wants0 != 0ull) {
+            // ---- bounding boxes of the four sub-groups (lanes that want nothing do not stretch them): SGPRs, and LDS for the fallback
+            float gl[4][3], gh[4][3];
+            {
+                const bool wants = thr >= 0.0f;
+                const float lx = row_fmin(wants ? px : inf), ly = row_fmin(wants ? py : inf), lz = row_fmin(wants ? pz : inf);
+                const float hx = row_fmax(wants ? px : -inf), hy = row_fmax(wants ? py : -inf), hz = row_fmax(wants ? pz : -inf);
+#pragma unroll
+                for (int g = 0; g < 4; g++) {
+                    gl[g][0] = bcast(lx, 16 * g + 15); gl[g][1] = bcast(ly, 16 * g + 15); gl[g][2] = bcast(lz, 16 * g + 15);
+                    gh[g][0] = bcast(hx, 16 * g + 15); gh[g][1] = bcast(hy, 16 * g + 15); gh[g][2] = bcast(hz, 16 * g + 15);
+                }
+                if ((lane & 15) == 15) {
+                    float *sb = const_cast<float *>(s_sb[lane >> 4]);
+                    sb[0] = lx; sb[1] = ly; sb[2] = lz; sb[3] = 0.f; sb[4] = hx; sb[5] = hy; sb[6] = hz; sb[7] = 0.f;
+                }
+            }
+            const float4 rootA = onodes[0], rootB = onodes[1];                            // (same address in every lane)
+            const uint32_t root_first = (uint32_t)__builtin_amdgcn_readfirstlane(__float_as_int(rootA.w));
+            const uint32_t root_packed = (uint32_t)__builtin_amdgcn_readfirstlane(__float_as_int(rootB.w));
+            bool done = false;
+            uint32_t dive_first = 0xFFFFFFFFu;          // first point of the leaf the dive scanned (a leaf is identified by it)
+            // ---- dive: a finite bound for every lane before the frontier is built (skipped when all lanes have one)
+            if (__ballot(thr == inf) != 0ull) {
+                const int mid = (wants0 >> 32) & 1ull ? 32 : (int)__ffsll((long long)wants0) - 1;
+                const float cx = bcast(px, mid), cy = bcast(py, mid), cz = bcast(pz, mid);
+                uint32_t packed = root_packed, first = root_first, level = 0;
+                while (((packed >> 24) & 15u) != 0u) {
+                    const uint32_t nch = (packed >> 24) & 15u, cf = packed & 0xFFFFFFu;
+                    uint32_t key = 0xFFFFFFFFu;
+                    float4 cA = make_float4(0.f, 0.f, 0.f, 0.f), cB = cA;
+                    if ((uint32_t)lane < nch) {
+                        const float4 *__restrict__ ch = onodes + 2 * ((size_t)s_off[level + 1] + cf + (uint32_t)lane);
+                        cA = ch[0]; cB = ch[1];
+                        key = (__float_as_uint(boxdist2(cx, cy, cz, cA, cB)) & ~7u) | (uint32_t)lane;
+                    }
+                    key = dpp_umin<0x111, 0xf>(key); key = dpp_umin<0x112, 0xf>(key); key = dpp_umin<0x114, 0xf>(key);      // lane 7: min of lanes 0..7
+                    const int cmin = __builtin_amdgcn_readlane((int)key, 7) & 7;
+                    packed = (uint32_t)__builtin_amdgcn_readlane(__float_as_int(cB.w), cmin);
+                    first = (uint32_t)__builtin_amdgcn_readlane(__float_as_int(cA.w), cmin);
+                    level++;
+                    if (DBG) cn.steps++;
+                }
+                const uint32_t cnt = packed & 0xFFFFFFu;
+                if (DBG) cn.points += cnt;
+                pkt_leaf_scalar<CERT>(tq, first, cnt, px, py, pz, b, cn.ties);
+                thr = fminf(thr, pkt_threshold(b.d2, pad));
+                done = (level == 0);               // the root itself is a leaf: everything has been scanned
+                dive_first = first;                // the sweep below skips this leaf (a second scan would count its points as ties)
+            }
+            // ---- breadth-first sweep
+            uint32_t nf = 0;
+            int cur = 0;
+            if (!done && ((root_packed >> 24) & 15u) != 0u) {
+                if (lane == 0) fr[0][0] = root_packed & 0x0FFFFFFFu;
+                nf = 1;
+            } else if (!done) {
+                // the root is a leaf and there was no dive
+                pkt_leaf_scalar<CERT>(tq, root_first, root_packed & 0xFFFFFFu, px, py, pz, b, cn.ties);
+                thr = fminf(thr, pkt_threshold(b.d2, pad));
+            }
+            __builtin_amdgcn_wave_barrier();
+            bool overflow = false;
+            uint32_t tg[4];
+            for (uint32_t level = 0; nf > 0 && !overflow; level++) {
+                uint32_t nn = 0;
+                const uint32_t off_next = s_off[level + 1];
+                {
+                    const uint32_t tb = (thr >= 0.0f) ? __float_as_uint(thr) + 1u : 0u;   // 0: the lane wants nothing; else bits + 1 (a bound of 0 still admits gap 0)
+                    const uint32_t r = row_umax(tb);
+#pragma unroll
+                    for (int g = 0; g < 4; g++) tg[g] = (uint32_t)__builtin_amdgcn_readlane((int)r, 16 * g + 15);
+                }
+                for (uint32_t f0 = 0; f0 < nf; f0 += 8) {
+                    if (DBG) { cn.steps++; steps_pk++; }
+                    const uint32_t f = f0 + (uint32_t)(lane >> 3), c = (uint32_t)(lane & 7);
+                    const uint32_t pkd = (f < nf) ? fr[cur][f] : 0u;
+                    const bool valid = c < ((pkd >> 24) & 15u);
+                    float4 cA = make_float4(0.f, 0.f, 0.f, 0.f), cB = cA;
+                    bool keep = false;
+                    if (valid) {
+                        const float4 *__restrict__ ch = onodes + 2 * ((size_t)off_next + (pkd & 0xFFFFFFu) + c);
+                        cA = ch[0]; cB = ch[1];
+#pragma unroll
+                        for (int g = 0; g < 4; g++) {
+                            // gap between the child's box and the sub-group's box: a lower bound of boxdist2 for each of its lanes
+                            const float gx = fmaxf(fmaxf(cA.x - gh[g][0], gl[g][0] - cB.x), 0.0f);
+                            const float gy = fmaxf(fmaxf(cA.y - gh[g][1], gl[g][1] - cB.y), 0.0f);
+                            const float gz = fmaxf(fmaxf(cA.z - gh[g][2], gl[g][2] - cB.z), 0.0f);
+                            keep |= __float_as_uint((gx * gx + gy * gy) + gz * gz) < tg[g];
+                        }
+                    }
+                    const uint32_t cpk = (uint32_t)__float_as_int(cB.w);
+                    const bool isleaf = ((cpk >> 24) & 15u) == 0u;
+                    const bool keepL = keep && isleaf, keepI = keep && !isleaf;
+                    if (DBG) cn.nodes += (unsigned long long)__popcll(__ballot(valid));
+                    // internal survivors -> next frontier
+                    const unsigned long long mI = __ballot(keepI);
+                    if (mI) {
+                        const uint32_t slot = nn + __builtin_amdgcn_mbcnt_hi((uint32_t)(mI >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mI, 0u));
+                        if (keepI && slot < (uint32_t)kFrontCap) fr[cur ^ 1][slot] = cpk & 0x0FFFFFFFu;
+                        nn += (uint32_t)__popcll(mI);
+                    }
+                    // leaf survivors: their lanes fetch the points (all leaves of the step at once), then one leaf at a time
+                    unsigned long long mL = __ballot(keepL);
+                    if (mL) {
+                        float4 pt[8];
+                        if (keepL) {
+                            const float4 *__restrict__ lp = tq + (uint32_t)__float_as_int(cA.w);
+#pragma unroll
+                            for (int k = 0; k < 8; k++) pt[k] = lp[k];                    // (tq is padded by 8 entries)
+                        }
+                        bool scanned = false;
+                        while (mL) {
+                            const int src = (int)__ffsll((long long)mL) - 1;
+                            mL &= mL - 1ull;
+                            if (DBG) cn.leaves++;
+                            const uint32_t first = (uint32_t)__builtin_amdgcn_readlane(__float_as_int(cA.w), src);
+                            if (first == dive_first) continue;                                   // scanned by the dive already
+                            float4 lo, hi;
+                            lo.x = bcast(cA.x, src); lo.y = bcast(cA.y, src); lo.z = bcast(cA.z, src);
+                            hi.x = bcast(cB.x, src); hi.y = bcast(cB.y, src); hi.z = bcast(cB.z, src);
+                            if (__ballot(boxdist2(px, py, pz, lo, hi) <= thr) == 0ull) { if (DBG) cn.rejected++; continue; }
+                            const uint32_t cnt = (uint32_t)__builtin_amdgcn_readlane((int)cpk, src) & 0xFFFFFFu;
+                            if (DBG) cn.points += cnt;
+                            pkt_leaf_regs<CERT>(tq, pt, src, first, min(cnt, 8u), px, py, pz, b, cn.ties);
+                            if (cnt > 8u) pkt_leaf_scalar<CERT>(tq, first + 8u, cnt - 8u, px, py, pz, b, cn.ties);
+                            thr = fminf(thr, pkt_threshold(b.d2, pad));
+                            scanned = true;
+                        }
+                        if (scanned) {
+                            const uint32_t tb = (thr >= 0.0f) ? __float_as_uint(thr) + 1u : 0u;
+                            const uint32_t r = row_umax(tb);
+#pragma unroll
+                            for (int g = 0; g < 4; g++) tg[g] = (uint32_t)__builtin_amdgcn_readlane((int)r, 16 * g + 15);
+                        }
+                    }
+                }
+                if (nn > (uint32_t)kFrontCap) overflow = true;
+                nf = nn;
+                cur ^= 1;
+                __builtin_amdgcn_wave_barrier();
+            }
+            if (overflow) {
+                // a frontier outgrew its LDS slot: finish depth-first from the root with the bounds reached so far (exact)
+                cn.overflow++;
+                ovf_pk = true;
+                pkt_dfs<CERT>(onodes, tq, s_off, s_buf, s_sb, px, py, pz, b, thr, pad, cn);
+            }
+        }
+        if (active) {
+            a.pos_out[i] = b.pos;
+            a.d2_out[i] = b.d2;
+            float L = 0.0f;
+            if (CERT && pad > 0.0f && b.pos >= 0) {
+                const float d1 = sqrtf(b.d2);
+                const float Lc = fminf(sqrtf(__uint_as_float(b.second)) * 0.999999f, (d1 + pad) * 0.99999f);
+                L = (Lc > d1 * 1.000001f) ? Lc : 0.0f;
+            }
+            a.cert[i] = make_float4(px, py, pz, L);
+            if (b.pos >= 0) store_pair_record(a, ix, i, b.pos);
+            else a.pairrec[2 * (size_t)i + 1] = make_float4(0.f, 0.f, 0.f, 1.f);
+        }
+        if (DBG && lane == 0) {
+            const unsigned long long dt = __builtin_amdgcn_s_memrealtime() - t_start;      // 100 MHz ticks
+            atomicMax(ix.dbg + 6, dt);
+            atomicAdd(ix.dbg + 7, dt);
+            if (ix.dbg_trace && (size_t)pk < ((size_t)1 << 21)) {
+                ix.dbg_trace[2 * (size_t)pk] = t_start;
+                ix.dbg_trace[2 * (size_t)pk + 1] = (dt << 32) | ((unsigned long long)(steps_pk & 0xFFFFFFu) << 8) | ((unsigned long long)SRC << 1) | (unsigned long long)(ovf_pk ? 1u : 0u);
+            }
+        }
+    }
+    if (DBG && lane == 0) {
+        atomicAdd(ix.dbg + 0, cn.steps);
+        atomicAdd(ix.dbg + 1, cn.overflow);
+        atomicAdd(ix.dbg + 2, cn.ties);
+        atomicAdd(ix.dbg + 3, cn.points);
+        atomicAdd(ix.dbg + 4, cn.nodes + cn.leaves);
+        atomicAdd(ix.dbg + 5, cn.rejected);
+    }
+}
+
+// first pass of an alignment: no previous pairs, every query is searched -- packets over the whole (sorted) share
+void launch_accumulate(const PassArgs &a, const float4 *tn, int blocks, hipStream_t s);
+
+void launch_pass_tree_first(const PassArgs &a_in, const TargetIndex &ix, const WorkLists &wl, int acc_blocks, hipStream_t s, hipEvent_t *ev)
+{
+    PassArgs a = a_in;
+    a.refresh_records = 1;
+    const uint32_t npk = (a.n + 63u) / 64u;
+    const uint32_t nbp = ((npk + 7u) / 8u) * 8u;
+    if (ev) { hipEventRecord(ev[0], s); hipEventRecord(ev[1], s); hipEventRecord(ev[2], s); }
+    static const uint32_t lds_pad = getenv("SYMMICP_PACKET_LDS_PAD") ? (uint32_t)atol(getenv("SYMMICP_PACKET_LDS_PAD")) : 0u;      // occupancy experiments
+    if (ix.dbg) hipLaunchKernelGGL((k_search_packet<PKT_ALL, false, true>), dim3(nbp), dim3(64), lds_pad, s, a, ix, wl.work, 0.0f);
+    else hipLaunchKernelGGL((k_search_packet<PKT_ALL, false, false>), dim3(nbp), dim3(64), lds_pad, s, a, ix, wl.work, 0.0f);
+    if (ev) hipEventRecord(ev[3], s);
+    launch_accumulate(a, ix.tn, acc_blocks, s);
+    if (ev) hipEventRecord(ev[4], s);
+}
+
+}  // namespace symmicp

@@ -16,6 +16,8 @@
 // nearest-neighbour choices compare bit for bit.
 #include <cstdlib>
 #include "symmicp_internal.h"
+#include "device_common.h"
+#include "oct_walk.h"
 #pragma clang fp contract(off)
 
 namespace symmicp {
@@ -23,28 +25,6 @@ namespace symmicp {
 // ---------------------------------------------------------------------------
 // small device helpers
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ float xf_row(const float *m, float x, float y, float z, float w)
-{
-    // ((m0*x + m1*y) + m2*z) + m3*w      (func.cpp:111-118, k sequential)
-    return ((m[0] * x + m[1] * y) + m[2] * z) + m[3] * w;
-}
-
-__device__ __forceinline__ float dist2(float ax, float ay, float az, float bx, float by, float bz)
-{
-    float dx = ax - bx, dy = ay - by, dz = az - bz;
-    return (dx * dx + dy * dy) + dz * dz;
-}
-
-// squared distance from a point to an axis-aligned box, same expression shape as
-// dist2 so that (in fp32) boxdist2 <= dist2 to every point stored inside the box.
-__device__ __forceinline__ float boxdist2(float px, float py, float pz, const float4 &lo, const float4 &hi)
-{
-    float dx = fmaxf(fmaxf(lo.x - px, px - hi.x), 0.0f);
-    float dy = fmaxf(fmaxf(lo.y - py, py - hi.y), 0.0f);
-    float dz = fmaxf(fmaxf(lo.z - pz, pz - hi.z), 0.0f);
-    return (dx * dx + dy * dy) + dz * dz;
-}
-
 struct Acc {
     double v[kNAcc];
 };
@@ -273,139 +253,6 @@ __device__ __forceinline__ uint32_t spread3(uint32_t v)
     return v;
 }
 
-struct Best {
-    float d2;
-    int32_t pos;      // sorted position
-    int32_t row;      // original target row (tie-break key)
-};
-
-__device__ __forceinline__ void test_point(Best &b, const float4 &q, int32_t pos, float px, float py, float pz)
-{
-    const float d2 = dist2(px, py, pz, q.x, q.y, q.z);
-    if (d2 <= b.d2) {                                  // rarely taken: most candidates are not better
-        const int32_t row = __float_as_int(q.w);
-        if (d2 < b.d2 || row < b.row) { b.d2 = d2; b.pos = pos; b.row = row; }
-    }
-}
-
-
-// ---- exact walk of the sparse octree (TargetIndex::onodes) ------------------------------------------
-// Nodes are octree cells that hold points; siblings are disjoint, so the box distance separates them at every
-// level and the first root-to-leaf descent already lands next to the answer (the run tree above needs ~30 more
-// expansions for that on a surface cloud: runs of the sorted order straddle the jumps of the Z curve and their
-// boxes overlap).  Visiting a node: a leaf scans its (<= 8, unless duplicates pile up in one finest cell) points;
-// an internal node loads its <= 8 child boxes (contiguous in the next level), enters the nearest one that can still
-// win and remembers the others as (child_first << 8 | 8-bit mask) in a register stack, one word per level.  Coming
-// back to a sibling, its box is tested again against the (now smaller) best.
-struct OctStack {
-    uint32_t s[kMortonBits];
-    __device__ __forceinline__ void push(uint32_t w)
-    {
-#pragma unroll
-        for (int k = kMortonBits - 1; k > 0; k--) s[k] = s[k - 1];
-        s[0] = w;
-    }
-    __device__ __forceinline__ void pop()
-    {
-#pragma unroll
-        for (int k = 0; k < kMortonBits - 1; k++) s[k] = s[k + 1];
-        s[kMortonBits - 1] = 0;
-    }
-};
-
-// One loop iteration = one node visit, and a leaf is visited with the SAME code as an internal node: its points
-// are read as degenerate boxes (lo = hi = point), for which boxdist2 is bit-for-bit dist2.  Lanes of a wave sit at
-// different nodes of different kinds, but now they all execute one common body (load <= 8 entities, 8 distances)
-// instead of serialising a leaf path, an internal path and a sibling path each trip.
-// BUDGETED: give up after `budget` node visits (return value > budget); b then holds the best point seen so far, a valid
-// bound for whoever finishes the query.  The plain instantiation carries no trace of it (the walk kernel is
-// register-bound: the extra state costs the unbudgeted walk 4 %).
-template <bool BUDGETED = false>
-__device__ __forceinline__ uint32_t oct_walk(const TargetIndex &ix, float px, float py, float pz, Best &b, uint32_t budget = 0xFFFFFFFFu)
-{
-    const float inf = __int_as_float(0x7f800000);
-    OctStack st;
-#pragma unroll
-    for (int k = 0; k < kMortonBits; k++) st.s[k] = 0;
-    int L = 0;
-    uint32_t idx = 0;
-    uint32_t visits = 0;
-    while (true) {
-        visits++;
-        if (BUDGETED && visits > budget) return visits;
-        const float4 *__restrict__ nd = ix.onodes + 2 * ((size_t)ix.olevel_off[L] + idx);
-        const float4 hA = nd[0], hB = nd[1];
-        const uint32_t first = (uint32_t)__float_as_int(hA.w);
-        const uint32_t packed = (uint32_t)__float_as_int(hB.w);
-        // the header is the node's own box: a sibling taken from the pending list is re-tested here against the
-        // current best, so the list pop below needs no loads of its own
-        const bool alive = boxdist2(px, py, pz, hA, hB) <= b.d2;
-        const uint32_t nch = packed >> 24;
-        const bool leaf = (nch == 0);
-        const uint32_t cf = packed & 0xFFFFFFu;                 // internal: first child; leaf: number of points
-        const uint32_t total = alive ? (leaf ? cf : nch) : 0u;
-        // entity e of this node: leaf -> point tq[first + e] ; internal -> child box onodes[level L+1][cf + e]
-        const float4 *__restrict__ ent = leaf ? (ix.tq + first) : (ix.onodes + 2 * ((size_t)ix.olevel_off[L + 1] + cf));
-        const int stride = leaf ? 1 : 2;
-        bool descended = false;
-        for (uint32_t e0 = 0; e0 < total; e0 += 8) {           // more than one trip only for > 8 duplicates in a finest cell
-            // All lanes run the same straight-line body over 8 entity slots; slots past the end re-read the last
-            // entity (harmless duplicate) instead of being predicated off.  One running arg-min serves both kinds:
-            // for a leaf it is the candidate point (ties -> lowest row), for an internal node the child to enter.
-            const uint32_t last = total - 1 - e0;               // index of the last valid slot in this group (may be >= 8)
-            uint32_t mask = 0;
-            int ec = 0, erow = 0x7fffffff;
-            float ed = inf;
-#pragma unroll
-            for (int h = 0; h < 8; h += 4) {
-                float4 lo[4], hi[4];
-#pragma unroll
-                for (int c = 0; c < 4; c++) {
-                    const uint32_t e = e0 + min((uint32_t)(h + c), last);
-                    lo[c] = ent[e * stride];
-                    hi[c] = ent[e * stride + (stride - 1)];
-                }
-#pragma unroll
-                for (int c = 0; c < 4; c++) {
-                    // branch-free on purpose (selects, not jumps): eight tiny divergent branches per visit cost more
-                    // scalar/exec bookkeeping than the work they skip
-                    const float d = boxdist2(px, py, pz, lo[c], hi[c]);
-                    const int row = __float_as_int(lo[c].w);
-                    mask |= (d <= b.d2) ? (1u << (h + c)) : 0u;
-                    const bool better = (d < ed) | ((d == ed) & (row < erow));
-                    ed = better ? d : ed;
-                    erow = better ? row : erow;
-                    ec = better ? (h + c) : ec;
-                }
-            }
-            if (last < 7u) mask &= (2u << last) - 1u;           // drop the duplicate slots
-            if (leaf) {
-                if (ed <= b.d2 && (ed < b.d2 || erow < b.row)) { b.d2 = ed; b.row = erow; b.pos = (int32_t)(first + e0 + min((uint32_t)ec, last)); }
-            } else if (mask) {
-                st.push((cf << 8) | (mask & ~(1u << ec)));
-                L++;
-                idx = cf + (uint32_t)ec;
-                descended = true;
-            }
-        }
-        if (descended) continue;
-        // node done: next pending sibling, climbing as levels run out
-        bool found = false;
-        while (L > 0) {
-            const uint32_t w = st.s[0];
-            const uint32_t mask = w & 0xFFu;
-            if (mask == 0) { st.pop(); L--; continue; }
-            const int c = __ffs((int)mask) - 1;
-            st.s[0] = w & ~(1u << c);
-            idx = (w >> 8) + (uint32_t)c;
-            found = true;
-            break;
-        }
-        if (!found) break;
-    }
-    return visits;
-}
-
 // ---------------------------------------------------------------------------
 // The nearest-neighbour pass (SYMMICP_CORR_TREE) is three kernels plus the final reduce:
 //   k_search_cells  thread = query: pair certificate / cell scan / two-round cell probe; what it cannot finish goes
@@ -419,57 +266,11 @@ __device__ __forceinline__ uint32_t oct_walk(const TargetIndex &ix, float px, fl
 // ---------------------------------------------------------------------------
 constexpr int kWaveFrontier = 512;        // frontier nodes per level in the wave-per-entry walk
 
-__device__ __forceinline__ void sl_push(const ShardList &L, uint32_t shard, uint32_t v)
-{
-    const uint32_t k = atomicAdd(L.counts + shard * kShardStride, 1u);
-    L.items[(size_t)shard * L.cap + k] = v;
-}
-
-// A list is consumed as the concatenation of its shards (balances consumers when shards are unevenly filled).
-// sl_prefix: every thread of the block calls it once; pre[0..64] = exclusive prefix sums of the shard counts.
-__device__ __forceinline__ void sl_prefix(const ShardList &L, uint32_t *pre /* __shared__ [kShards + 1] */)
-{
-    if (threadIdx.x < kShards) {
-        uint32_t v = L.counts[threadIdx.x * kShardStride];
-#pragma unroll
-        for (int off = 1; off < kShards; off <<= 1) {
-            const uint32_t u = __shfl_up(v, off, 64);
-            if ((int)threadIdx.x >= off) v += u;
-        }
-        pre[threadIdx.x + 1] = v;
-        if (threadIdx.x == 0) pre[0] = 0;
-    }
-    __syncthreads();
-}
-
-// entry number g of the concatenated list; false when g is past the end
-__device__ __forceinline__ bool sl_locate(const ShardList &L, const uint32_t *pre, uint32_t g, uint32_t &item)
-{
-    if (g >= pre[kShards]) return false;
-    int lo = 0;
-#pragma unroll
-    for (int step = kShards / 2; step > 0; step >>= 1)
-        if (pre[lo + step] <= g) lo += step;
-    item = L.items[(size_t)lo * L.cap + (g - pre[lo])];
-    return true;
-}
-
-__device__ __forceinline__ uint32_t xcd_remap(uint32_t b, uint32_t nb_padded)
-{
-    return (b & 7u) * (nb_padded >> 3) + (b >> 3);
-}
-
 // Every pair keeps a private copy of its target's 32-byte (point, normal) record, so that k_accumulate streams instead of
 // gathering through `pos`: once an alignment has converged almost no pair changes, and the gather was what bounded
 // that kernel.  k_search_cells refreshes the copy of a pair it settles itself and marks the copy STALE (w = 2 in the
 // normal slot) when it hands the query to the tree walk; k_accumulate then gathers that pair once more and refreshes the
 // copy itself (the walk kernel is register-bound and stays untouched).  w = 1: the point has no target at all.
-__device__ __forceinline__ void store_pair_record(const PassArgs &a, const TargetIndex &ix, uint32_t i, int32_t pos)
-{
-    a.pairrec[2 * (size_t)i] = ix.tn[2 * (size_t)pos];
-    a.pairrec[2 * (size_t)i + 1] = ix.tn[2 * (size_t)pos + 1];
-}
-
 // squared gap (minus the safety margin) between the query coordinate and the cell [lo, lo+h) on one axis
 __device__ __forceinline__ float axis_gap2(float p, float origin, int c, float h, float margin)
 {
@@ -991,222 +792,6 @@ __global__ __launch_bounds__(kWalkThreads, 6) void k_search_walk(PassArgs a, Tar
     }
 }
 
-// ---------------------------------------------------------------------------
-// k_search_packet: exact nearest neighbours for 64 queries at a time (one wave = one PACKET of 64 consecutive
-// queries of the Morton-sorted source, i.e. a compact patch of the cloud).
-//
-// The per-thread walk above pays for every node visit with 64 lanes' worth of divergent 16-byte loads and ~350
-// vector instructions, and a wave is as slow as its slowest lane.  Here the TRAVERSAL is wave-uniform (one stack in LDS,
-// scalar control flow) and only the distance tests are per lane:
-//   pop a node (its 32-byte record travels on the stack, so a pop needs no global load)
-//     every lane tests the node's box against its own query and bound; no lane wants it -> next pop
-//   leaf:     the leaf's points are wave-uniform loads; each lane tests each point (14 VALU per point for 64 queries)
-//   internal: lanes 0..7 load the <= 8 child records (one coalesced 256-byte read), test them against the packet's
-//             bounding box and the loosest bound of any lane, and push the survivors -- nearest on top (the order of
-//             the others does not matter: measured in scratch/sim_packet.py, sorted vs nearest-on-top: +2 % visits)
-// A node is expanded iff at least one lane needs it, so the packet visits the UNION of its lanes' node sets, but a
-// visit costs one wave-wide instruction stream instead of 64 divergent ones.  Exactness: a box is skipped only when
-// boxdist2 (same monotone fp32 expression as dist2) exceeds the lane's bound for every lane; ties resolve to the lowest
-// original row through the (d2, row) comparison, as in brute force.
-// `pad` > 0: scan everything within (nearest + pad), so that the result carries a pair certificate (see k_search_cells).
-// ---------------------------------------------------------------------------
-constexpr int kPktStack = 128;            // >= 7 * octree levels + 1
-
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ float dpp_mov_f32(float x)
-{
-    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(x), __float_as_int(x), CTRL, ROW_MASK, 0xf, false));
-}
-
-// wave-wide max / min on the DPP network; every lane must be active.  Result is uniform (read from lane 63).
-__device__ __forceinline__ float wave_max_dpp(float x)
-{
-    x = fmaxf(x, dpp_mov_f32<0x111, 0xf>(x));
-    x = fmaxf(x, dpp_mov_f32<0x112, 0xf>(x));
-    x = fmaxf(x, dpp_mov_f32<0x114, 0xf>(x));
-    x = fmaxf(x, dpp_mov_f32<0x118, 0xf>(x));
-    x = fmaxf(x, dpp_mov_f32<0x142, 0xa>(x));
-    x = fmaxf(x, dpp_mov_f32<0x143, 0xc>(x));
-    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 63));
-}
-
-__device__ __forceinline__ float wave_min_dpp(float x)
-{
-    x = fminf(x, dpp_mov_f32<0x111, 0xf>(x));
-    x = fminf(x, dpp_mov_f32<0x112, 0xf>(x));
-    x = fminf(x, dpp_mov_f32<0x114, 0xf>(x));
-    x = fminf(x, dpp_mov_f32<0x118, 0xf>(x));
-    x = fminf(x, dpp_mov_f32<0x142, 0xa>(x));
-    x = fminf(x, dpp_mov_f32<0x143, 0xc>(x));
-    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 63));
-}
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-// two 64-byte scalar loads from a wave-uniform address (hipcc does not count asm loads: the wait is part of the statement)
-__device__ __forceinline__ void sload_2x16(const void *p, f32x16 &a, f32x16 &b)
-{
-    asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx16 %1, %2, 0x40\n\ts_waitcnt lgkmcnt(0)" : "=&s"(a), "=&s"(b) : "s"(p) : "memory");
-}
-
-struct PktBest {
-    float d2, second;
-    int32_t row, pos;
-};
-
-__device__ __forceinline__ void pkt_test_point(PktBest &b, float px, float py, float pz, float qx, float qy, float qz, int32_t row, int32_t pos)
-{
-    const float d2 = dist2(px, py, pz, qx, qy, qz);
-    const bool better = (d2 < b.d2) | ((d2 == b.d2) & (row < b.row));
-    b.second = fminf(b.second, fmaxf(d2, b.d2));       // the loser of every comparison is a candidate for second-nearest
-    b.d2 = better ? d2 : b.d2;
-    b.row = better ? row : b.row;
-    b.pos = better ? pos : b.pos;
-}
-
-__device__ __forceinline__ float pkt_threshold(float d2, float pad)
-{
-    if (pad <= 0.0f) return d2;
-    const float rp = __builtin_amdgcn_sqrtf(d2) * 1.00001f + pad;
-    return rp * rp * 1.00001f;
-}
-
-// FROM_LIST = false: the packets are the queries [0, n) in order (first pass of an alignment: no previous pairs).
-// FROM_LIST = true:  the packets are consecutive entries of `list` (queries another kernel could not settle); the
-//                    previous pair's current distance (d2_out[i], provisional pos_out[i]) bounds each lane's search.
-template <bool FROM_LIST>
-__global__ __launch_bounds__(64, 8) void k_search_packet(PassArgs a, TargetIndex ix, ShardList list, float pad)
-{
-    __shared__ float4 stk[kPktStack][2];
-    __shared__ uint32_t s_off[kMortonBits + 2];
-    __shared__ uint32_t pre[kShards + 1];
-    const int lane = threadIdx.x;
-    const float inf = __int_as_float(0x7f800000);
-    if (lane < kMortonBits + 2) s_off[lane] = ix.olevel_off[lane];
-    uint32_t npk;
-    if (FROM_LIST) { sl_prefix(list, pre); npk = (pre[kShards] + 63u) >> 6; }
-    else { __syncthreads(); npk = (a.n + 63u) >> 6; }
-    const float4 *__restrict__ tq = ix.tq;
-    const float4 *__restrict__ onodes = ix.onodes;
-    unsigned long long c_int = 0, c_leaf = 0, c_rej = 0, c_pts = 0;
-    for (uint32_t pk = FROM_LIST ? blockIdx.x : xcd_remap(blockIdx.x, gridDim.x); pk < npk; pk += gridDim.x) {
-        uint32_t i = pk * 64u + (uint32_t)lane;
-        bool active;
-        if (FROM_LIST) active = sl_locate(list, pre, i, i);
-        else active = i < a.n;
-        float px = 0.f, py = 0.f, pz = 0.f;
-        PktBest b;
-        b.d2 = inf; b.second = inf; b.row = 0x7fffffff; b.pos = -1;
-        float thr = -1.0f;                 // prune bound on d2; -1: this lane wants nothing
-        if (active) {
-            const float x = a.in.x[i], y = a.in.y[i], z = a.in.z[i];
-            px = xf_row(a.X.m + 0, x, y, z, 1.0f); py = xf_row(a.X.m + 4, x, y, z, 1.0f); pz = xf_row(a.X.m + 8, x, y, z, 1.0f);
-            thr = inf;
-            if (FROM_LIST) {
-                // the provisional pair only bounds the search: its point is met again in the scan and wins (or ties) there
-                const float d0 = a.d2_out[i];
-                if (a.pos_out[i] >= 0 && d0 < inf) thr = pkt_threshold(d0, pad);
-            }
-            if (!((px == px) & (py == py) & (pz == pz))) { thr = -1.0f; }      // NaN query: no pair
-        }
-        // the packet's bounding box (lanes that want nothing do not stretch it)
-        const bool wants = thr >= 0.0f;
-        const float qlx = wave_min_dpp(wants ? px : inf), qly = wave_min_dpp(wants ? py : inf), qlz = wave_min_dpp(wants ? pz : inf);
-        const float qhx = wave_max_dpp(wants ? px : -inf), qhy = wave_max_dpp(wants ? py : -inf), qhz = wave_max_dpp(wants ? pz : -inf);
-        float thr_max = wave_max_dpp(thr);
-        int sp = 0;
-        if (thr_max >= 0.0f) {
-            if (lane == 0) {
-                float4 rA = onodes[0], rB = onodes[1];
-                stk[0][0] = rA; stk[0][1] = rB;           // level 0 in bits 28..31 of the packed word: already 0
-            }
-            sp = 1;
-        }
-        __builtin_amdgcn_wave_barrier();
-        while (sp > 0) {
-            sp--;
-            const float4 nA = stk[sp][0], nB = stk[sp][1];
-            const bool want = boxdist2(px, py, pz, nA, nB) <= thr;
-            if (__ballot(want) == 0ull) { c_rej++; continue; }
-            const uint32_t first = (uint32_t)__builtin_amdgcn_readfirstlane(__float_as_int(nA.w));
-            const uint32_t packed = (uint32_t)__builtin_amdgcn_readfirstlane(__float_as_int(nB.w));
-            const uint32_t level = packed >> 28, nch = (packed >> 24) & 15u, cf = packed & 0xFFFFFFu;
-            if (nch == 0) {
-                // leaf: cf points starting at tq[first]; wave-uniform loads, 8 at a time
-                c_leaf++; c_pts += cf;
-                for (uint32_t e0 = 0; e0 < cf; e0 += 8) {
-                    const uint32_t m = min(cf - e0, 8u);
-                    // 8 points = 128 bytes through the scalar cache (tq is padded by 8 entries); operands of the
-                    // distance tests are then SGPRs: no broadcast, no vector-memory traffic
-                    f32x16 qa, qb;
-                    sload_2x16(tq + first + e0, qa, qb);
-#pragma unroll
-                    for (int k = 0; k < 4; k++)
-                        if ((uint32_t)k < m) pkt_test_point(b, px, py, pz, qa[4 * k], qa[4 * k + 1], qa[4 * k + 2], __float_as_int(qa[4 * k + 3]), (int32_t)(first + e0 + k));
-#pragma unroll
-                    for (int k = 0; k < 4; k++)
-                        if ((uint32_t)(k + 4) < m) pkt_test_point(b, px, py, pz, qb[4 * k], qb[4 * k + 1], qb[4 * k + 2], __float_as_int(qb[4 * k + 3]), (int32_t)(first + e0 + 4 + k));
-                }
-                thr = fminf(thr, pkt_threshold(b.d2, pad));
-                thr_max = wave_max_dpp(thr);
-            } else {
-                c_int++;
-                float bbd = inf;
-                float4 cA = make_float4(0.f, 0.f, 0.f, 0.f), cB = cA;
-                const bool mine = (uint32_t)lane < nch;
-                if (mine) {
-                    const float4 *__restrict__ ch = onodes + 2 * ((size_t)s_off[level + 1] + cf + (uint32_t)lane);
-                    cA = ch[0]; cB = ch[1];
-                    // distance between the child's box and the packet's box (lower bound for every lane)
-                    const float gx = fmaxf(fmaxf(cA.x - qhx, qlx - cB.x), 0.0f);
-                    const float gy = fmaxf(fmaxf(cA.y - qhy, qly - cB.y), 0.0f);
-                    const float gz = fmaxf(fmaxf(cA.z - qhz, qlz - cB.z), 0.0f);
-                    bbd = (gx * gx + gy * gy) + gz * gz;
-                }
-                const bool keep = mine && bbd <= thr_max;
-                const uint32_t mask = (uint32_t)__ballot(keep);
-                if (mask) {
-                    // nearest survivor on top of the stack, the others below it in lane order
-                    const uint32_t key = keep ? ((__float_as_uint(bbd) & ~7u) | (uint32_t)lane) : 0xFFFFFFFFu;
-                    uint32_t kmin = key;
-                    kmin = min(kmin, (uint32_t)__builtin_amdgcn_update_dpp((int)kmin, (int)kmin, 0x111, 0xf, 0xf, false));   // row_shr:1
-                    kmin = min(kmin, (uint32_t)__builtin_amdgcn_update_dpp((int)kmin, (int)kmin, 0x112, 0xf, 0xf, false));   // row_shr:2
-                    kmin = min(kmin, (uint32_t)__builtin_amdgcn_update_dpp((int)kmin, (int)kmin, 0x114, 0xf, 0xf, false));   // row_shr:4 -> lane 7 holds min of lanes 0..7
-                    const uint32_t cmin = (uint32_t)__builtin_amdgcn_readlane((int)kmin, 7) & 7u;
-                    const uint32_t nk = (uint32_t)__popc(mask);
-                    const uint32_t rank = (uint32_t)__popc(mask & ((1u << (lane & 7)) - 1u));
-                    const uint32_t rmin = (uint32_t)__popc(mask & ((1u << cmin) - 1u));
-                    if (keep) {
-                        const uint32_t slot = ((uint32_t)lane == cmin) ? nk - 1u : (rank > rmin ? rank - 1u : rank);
-                        cB.w = __int_as_float((int)(((uint32_t)__float_as_int(cB.w) & 0x0FFFFFFFu) | ((level + 1u) << 28)));
-                        stk[sp + slot][0] = cA; stk[sp + slot][1] = cB;
-                    }
-                    sp += (int)nk;
-                }
-                __builtin_amdgcn_wave_barrier();
-            }
-        }
-        if (active) {
-            a.pos_out[i] = b.pos;
-            a.d2_out[i] = b.d2;
-            float L = 0.0f;
-            if (pad > 0.0f && b.pos >= 0) {
-                const float d1 = sqrtf(b.d2);
-                const float Lc = fminf(sqrtf(b.second) * 0.999999f, (d1 + pad) * 0.99999f);
-                L = (Lc > d1 * 1.000001f) ? Lc : 0.0f;
-            }
-            a.cert[i] = make_float4(px, py, pz, L);
-            if (b.pos >= 0) store_pair_record(a, ix, i, b.pos);
-            else a.pairrec[2 * (size_t)i + 1] = make_float4(0.f, 0.f, 0.f, 1.f);
-        }
-    }
-    if (ix.dbg && lane == 0) {
-        atomicAdd(ix.dbg + 4, c_int + c_leaf);
-        atomicAdd(ix.dbg + 5, c_rej);
-        atomicAdd(ix.dbg + 3, c_pts);
-    }
-}
-
 // The pair's distance is recomputed from the gathered q (bit-identical to the stored one) instead of being read.
 // (A 4-points-per-thread variant with 16-byte column loads was measured and is no faster: the two 16-byte gathers per
 // pair bound this kernel, not the column loads.  Few blocks are: each one ends in a 40-value block reduction.)
@@ -1454,18 +1039,9 @@ void launch_pass_tree_split(const PassArgs &a_in, const TargetIndex &ix, const W
     if (ev) hipEventRecord(ev[4], s);
 }
 
-// first pass of an alignment: no previous pairs, every query is searched -- packets over the whole (sorted) share
-void launch_pass_tree_first(const PassArgs &a_in, const TargetIndex &ix, const WorkLists &wl, int acc_blocks, hipStream_t s, hipEvent_t *ev)
+void launch_accumulate(const PassArgs &a, const float4 *tn, int blocks, hipStream_t s)
 {
-    PassArgs a = a_in;
-    a.refresh_records = 1;
-    const uint32_t npk = (a.n + 63u) / 64u;
-    const uint32_t nbp = ((npk + 7u) / 8u) * 8u;
-    if (ev) { hipEventRecord(ev[0], s); hipEventRecord(ev[1], s); hipEventRecord(ev[2], s); }
-    hipLaunchKernelGGL(k_search_packet<false>, dim3(nbp), dim3(64), 0, s, a, ix, wl.work, 0.0f);
-    if (ev) hipEventRecord(ev[3], s);
-    hipLaunchKernelGGL(k_accumulate, dim3(acc_blocks), dim3(kPassThreads), 0, s, a, ix.tn);
-    if (ev) hipEventRecord(ev[4], s);
+    hipLaunchKernelGGL(k_accumulate, dim3(blocks), dim3(kPassThreads), 0, s, a, tn);
 }
 
 void launch_final_reduce(const double *partials, int blocks, double *out_dev, double *out_host_mapped, uint32_t *ticket,

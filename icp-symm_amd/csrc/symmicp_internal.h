@@ -55,6 +55,7 @@ struct TargetIndex {
     float ox, oy, oz;        // grid origin (target bbox min)
     float h, inv_h;          // cell edge at glevel
     unsigned long long *dbg; // optional debug counters (SYMMICP_DEBUG_COUNTERS=1), else null
+    unsigned long long *dbg_trace;   // with dbg: per packet (start tick, ticks), (pops, hw id) -- 2 x u64 x 2 stages
     // sparse octree over the same sorted points: node = one Morton prefix (an octree cell that holds points),
     // levels 0 (root) .. kMortonBits.  Two float4 per node:
     //   A = (lo.x, lo.y, lo.z, first point as int bits)
@@ -144,7 +145,7 @@ void launch_oct_flags(const uint32_t *keys, uint32_t n, int level, uint32_t *nid
 void launch_exclusive_scan(uint32_t *data, uint32_t n, uint32_t *tile_ws /* >= ceil(n/2048) words */, hipStream_t s);
 void launch_oct_first(const uint32_t *keys, uint32_t n, int level, const uint32_t *nid, uint32_t *first, hipStream_t s);
 void launch_oct_nodes(int level, const float4 *tq, uint32_t n, const uint32_t *first, uint32_t n_nodes, const uint32_t *nid_next,
-                      uint32_t n_nodes_next, const float4 *nodes_next, float4 *nodes, hipStream_t s);
+                      uint32_t n_nodes_next, const float4 *nodes_next, float4 *nodes, uint32_t leaf_max, hipStream_t s);
 void launch_leaf_boxes(const float4 *tq, uint32_t n, float4 *boxes, uint32_t nleaf_padded, hipStream_t s);
 void launch_node_boxes(const float4 *child, uint32_t nchild_padded, float4 *parent, uint32_t nparent_padded, hipStream_t s);
 void launch_iota_f4(const float *x, const float *y, const float *z, const float *nx, const float *ny, const float *nz,

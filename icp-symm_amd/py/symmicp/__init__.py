@@ -15,7 +15,7 @@ import numpy as np
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(os.path.dirname(_PKG))           # icp-symm_amd/
-LIB_PATH = os.path.join(_ROOT, "lib", "libsymmicp.so")
+LIB_PATH = os.environ.get("SYMMICP_LIB") or os.path.join(_ROOT, "lib", "libsymmicp.so")      # SYMMICP_LIB: A/B builds in scratch runs
 
 NSUM = 40
 UNIQUE_ID_BYTES = 128

@@ -690,6 +690,21 @@ def test_forced_repair_path_in_a_subprocess(sym):
     assert " passed" in r.stdout
 
 
+@pytest.mark.parametrize("regime", ["packet", "walk"])
+def test_first_pass_regimes_forced_in_a_subprocess(sym, regime):
+    """The first pass of an alignment runs as 64-query packets (kernels_packet.hip) on surface-like targets and as the
+    per-thread octree walk on volume-like ones (engine.cpp, build_index).  SYMMICP_FIRST_PASS forces one regime on every
+    target -- volume clouds, tiny and ragged sizes, duplicates and ties, far queries included: pairs and distances must
+    stay bit-exact against the oracle either way."""
+    import subprocess
+    env = dict(os.environ, SYMMICP_FIRST_PASS=regime)
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
+                        "-k", "nn_exact or nn_scanlike or tree_follows_previous_pairs or randomised_exactness or partial_overlap or sharded_ranks or align_paper_recovers"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout
+
+
 def test_pair_certificates_stay_exact_under_small_and_large_moves(sym, oracle):
     """Pair certificates (k_search_cells): after a search a pair is re-used while the query has provably not
     moved far enough to change its nearest neighbour.  Drive the engine with a sequence of tiny and not-so-tiny
