@@ -150,6 +150,14 @@ struct symmicp_ctx {
     double *partials = nullptr, *d_sums = nullptr, *h_sums = nullptr, *h_sums_dev = nullptr;   // h_sums: 40 doubles + sequence word
     uint32_t *ticket = nullptr;          // ticket of the final reduce
     long long last_list_len = -1;        // work-list length of the last pass (all ranks); -1 = unknown (full walk grid)
+    long long last_uncertified = -1;     // TREE: pairs the last pass had to search again (all ranks); -1 = unknown
+    // device-driven runs of passes (run_batch): loop state in device memory, per-pass records + end flag in host-mapped memory
+    static constexpr int kRing = 65;
+    LoopState *d_loop = nullptr, *h_loop = nullptr, *h_loop_dev = nullptr;
+    LoopRecord *h_ring = nullptr, *h_ring_dev = nullptr;
+    unsigned long long *h_done = nullptr, *h_done_dev = nullptr;
+    unsigned long long batch_seq = 0;
+    int host_passes_since_bailout = 1000;   // batches resume after two clean host-driven passes
     unsigned long long seq = 0;
     // loop state
     bool begun = false;
@@ -299,6 +307,14 @@ int symmicp_create(const symmicp_config *cfg, symmicp_ctx **out)
               hipMalloc((void **)&c->ticket, sizeof(uint32_t)) == hipSuccess && hipMemset(c->ticket, 0, sizeof(uint32_t)) == hipSuccess &&
               hipHostGetDevicePointer((void **)&c->h_sums_dev, c->h_sums, 0) == hipSuccess &&
               std::memset(c->h_sums, 0, sizeof(double) * (kNSum + 8)) != nullptr &&
+              hipMalloc((void **)&c->d_loop, sizeof(LoopState)) == hipSuccess &&
+              hipHostMalloc((void **)&c->h_loop, sizeof(LoopState), hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess &&
+              hipHostGetDevicePointer((void **)&c->h_loop_dev, c->h_loop, 0) == hipSuccess &&
+              hipHostMalloc((void **)&c->h_ring, sizeof(LoopRecord) * symmicp_ctx::kRing, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess &&
+              hipHostGetDevicePointer((void **)&c->h_ring_dev, c->h_ring, 0) == hipSuccess &&
+              hipHostMalloc((void **)&c->h_done, 64, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess &&
+              hipHostGetDevicePointer((void **)&c->h_done_dev, c->h_done, 0) == hipSuccess &&
+              std::memset(c->h_done, 0, 64) != nullptr &&
               true;
     for (int k = 0; ok && k < symmicp_ctx::kEvRing * symmicp_ctx::kEvPer; k++) ok = hipEventCreateWithFlags(&c->ev[k], hipEventDisableSystemFence) == hipSuccess;      // timing only: no system-scope cache flush per record
     if (!ok) { symmicp_destroy(c); return SYMMICP_ERR_HIP; }
@@ -357,6 +373,10 @@ void symmicp_destroy(symmicp_ctx *c)
     free_source(c);
     hipFree(c->partials); hipFree(c->d_sums); hipFree(c->ticket); hipFree(c->arena.base); hipFree(c->keep.base);
     if (c->h_sums) hipHostFree(c->h_sums);
+    hipFree(c->d_loop);
+    if (c->h_loop) hipHostFree(c->h_loop);
+    if (c->h_ring) hipHostFree(c->h_ring);
+    if (c->h_done) hipHostFree(c->h_done);
     for (hipEvent_t e : c->ev) if (e) hipEventDestroy(e);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
@@ -831,9 +851,8 @@ static int shm_exchange(symmicp_ctx *c, double *rec)
 }
 
 // ---- one pass over the source share ------------------------------------------------------------
-static int run_pass(symmicp_ctx *c, const float Xapply[16], bool from_cur, bool writeback, bool first)
+static void fill_pass_args(symmicp_ctx *c, PassArgs &a, const float Xapply[16], bool from_cur, bool writeback, bool first)
 {
-    PassArgs a{};
     a.in = from_cur ? c->cur : c->src0;
     a.out = c->cur;
     a.n = c->n_loc;
@@ -852,14 +871,19 @@ static int run_pass(symmicp_ctx *c, const float Xapply[16], bool from_cur, bool 
     // identity pairing streams at the HBM roof: the per-pair distances (4 B/point) are only written on request
     a.d2_out = (c->cfg.corr == SYMMICP_CORR_IDENTITY) ? nullptr : c->d2;
     a.partials = c->partials;
-    {
-        a.cert = reinterpret_cast<float4 *>(c->cert);
-        a.pairrec = c->pairrec;
-        // sharded runs: the first pass over a small share is bound by its slowest walks, not by throughput
-        static const char *bw_env = std::getenv("SYMMICP_BUDGET_WALK");        // "0" never, "1" always (tests), unset: auto
-        a.budget_walk = bw_env ? (bw_env[0] == '1') : (first && c->nranks > 1 && c->n_loc < 400000u);
-        a.use_slack = (!first && c->cert && !std::getenv("SYMMICP_NO_CERT")) ? 1 : 0;
-    }
+    a.cert = reinterpret_cast<float4 *>(c->cert);
+    a.pairrec = c->pairrec;
+    // sharded runs: the first pass over a small share is bound by its slowest walks, not by throughput
+    static const char *bw_env = std::getenv("SYMMICP_BUDGET_WALK");        // "0" never, "1" always (tests), unset: auto
+    a.budget_walk = bw_env ? (bw_env[0] == '1') : (first && c->nranks > 1 && c->n_loc < 400000u);
+    a.use_slack = (!first && c->cert && !std::getenv("SYMMICP_NO_CERT")) ? 1 : 0;
+    a.loop = nullptr;
+}
+
+static int run_pass(symmicp_ctx *c, const float Xapply[16], bool from_cur, bool writeback, bool first)
+{
+    PassArgs a{};
+    fill_pass_args(c, a, Xapply, from_cur, writeback, first);
     int blocks = (int)((c->n_loc + kPassThreads - 1) / kPassThreads);
     int cap = 2048;
     if (const char *e = std::getenv("SYMMICP_PASS_BLOCKS")) cap = std::atoi(e);
@@ -967,6 +991,7 @@ static int run_pass(symmicp_ctx *c, const float Xapply[16], bool from_cur, bool 
     if (c->shm.slots) { if (int st = shm_exchange(c, c->h_sums)) return st; }
     // length of the work list (summed over ranks by the exchange, so every rank takes the same decision)
     long long list_len = (c->cfg.corr == SYMMICP_CORR_TREE) ? (long long)c->h_sums[kNSum - 1] : -1;
+    c->last_uncertified = (c->cfg.corr == SYMMICP_CORR_TREE && !first) ? (long long)c->h_sums[kNSum - 2] : -1;
     if (optimistic && list_len > 0) {
         // the walk was skipped but some queries needed it: their pairs are provisional, so are the sums
         c->st.kernel_launches[7]++;
@@ -998,9 +1023,151 @@ static int run_pass(symmicp_ctx *c, const float Xapply[16], bool from_cur, bool 
                      (long long)c->st.passes, h[1], h[2], h[6], h[7], h[0], h[3], list_len, h[4], h[5]);
     }
     std::memcpy(c->last.s, c->h_sums, sizeof(double) * kNSum);
-    if (c->cfg.corr == SYMMICP_CORR_TREE) c->last.s[kNSum - 1] = 0.0;      // that slot carried the list length, not a sum
+    if (c->cfg.corr == SYMMICP_CORR_TREE) c->last.s[kNSum - 1] = c->last.s[kNSum - 2] = 0.0;      // those slots carried the list length and the number of searched pairs, not sums
     c->last_list_len = list_len;
     c->st.passes++;
+    return SYMMICP_OK;
+}
+
+// ---- device-driven runs of passes -------------------------------------------------------------------
+// Once an alignment has converged a pass is ~30 us of kernels, and the host's share of an iteration (read the record back,
+// solve, launch) is as long as a kernel.  So symmicp_align hands runs of passes to the device: the solve of func.cpp:76-102
+// runs at the end of the reduce (k_reduce_solve, same source as the host solve: solve_core.h), the next pass reads its
+// transform from device memory, and the loop test of myicp.cpp:123 sets a stop flag every later kernel of the batch
+// honours.  The host solve stays the reference: anything but a clean, well-conditioned solve, and any pass that needs
+// the tree walk, stops the batch and the host loop takes that iteration (LOOP_HOST_SOLVE / LOOP_REDO_PASS).
+static bool batch_eligible(const symmicp_ctx *c)
+{
+    static const char *env = std::getenv("SYMMICP_HOST_LOOP");            // "1": never batch (A/B runs, tests)
+    if (env && env[0] == '1') return false;
+    if (c->cfg.host_loop) return false;
+    if (c->external_exchange || c->shm.slots) return false;               // those exchanges run on the host
+    if (c->timing == 2 || c->ix.dbg) return false;                        // per-kernel tables and debug counters: host loop
+    if (c->cfg.mode == SYMMICP_MODE_P2P) return false;                    // (3x3 SVD by Jacobi sweeps: host)
+    if (c->n_loc == 0) return false;
+    if (c->host_passes_since_bailout < 2) return false;
+    const bool incr = resolved_apply(c->cfg) == SYMMICP_APPLY_INCREMENTAL;
+    if (c->cfg.corr == SYMMICP_CORR_IDENTITY) return true;
+    // TREE: the fused pass is for converged alignments: nothing left for the tree walk and under 0.4 % of the pairs searched again
+    if (c->cfg.corr == SYMMICP_CORR_TREE)
+        return !incr && c->last_list_len == 0 && c->last_uncertified >= 0 && c->last_uncertified <= (long long)(c->n_s_total / 256) && c->cert && !std::getenv("SYMMICP_NO_CERT");
+    return false;
+}
+
+// Runs up to `want` iterations on the device.  On return c->iters, c->X and c->last describe the last COMPLETE pass, exactly as
+// if symmicp_step had been called (c->iters - iters_before) times; diffs_before[k] = the diff the reference prints before
+// iteration iters_before + 1 + k.  *small_step: the increment rule ended the alignment.
+static int run_batch(symmicp_ctx *c, int want, float *diffs_before, int *n_done, bool *small_step)
+{
+    *n_done = 0;
+    *small_step = false;
+    if (want > symmicp_ctx::kRing - 1) want = symmicp_ctx::kRing - 1;
+    if (want <= 0) return SYMMICP_OK;
+    const bool incr = resolved_apply(c->cfg) == SYMMICP_APPLY_INCREMENTAL;
+    const bool tree = c->cfg.corr == SYMMICP_CORR_TREE;
+    LoopConfig lc{};
+    lc.mode = c->cfg.mode; lc.fixed_iters = c->cfg.fixed_iters; lc.max_iters = c->iters + want; lc.incremental = incr ? 1 : 0; lc.tree = tree ? 1 : 0;
+    lc.diff_threshold = c->cfg.diff_threshold; lc.eps_rotation = c->cfg.eps_rotation; lc.eps_translation = c->cfg.eps_translation;
+    lc.nrm_w = (c->cfg.mode == SYMMICP_MODE_QUIRKS) ? 1.0f : 0.0f;
+    for (int k = 0; k < 3; k++) lc.pivot[k] = c->pivot[k];
+    lc.uncertified_limit = c->n_s_total / 64;
+    if (lc.max_iters > c->cfg.max_iters) lc.max_iters = c->cfg.max_iters;
+    const int it0 = c->iters;
+    float X0[16];
+    std::memcpy(X0, c->X, sizeof(X0));
+    // loop state as the host loop left it
+    LoopState ls{};
+    std::memcpy(ls.X, c->X, sizeof(ls.X));
+    for (int k = 0; k < 12; k++) ls.Xapply.m[k] = c->X[k];
+    ls.Xapply.nrm_w = lc.nrm_w;
+    ls.iters = it0;
+    *c->h_loop = ls;
+    HIP_TRY(c, hipMemcpyAsync(c->d_loop, c->h_loop, sizeof(LoopState), hipMemcpyHostToDevice, c->stream));
+    PassArgs a{};
+    fill_pass_args(c, a, c->X, /*from_cur=*/incr, /*writeback=*/incr, /*first=*/false);
+    a.loop = c->d_loop;
+    int blocks;
+    bool vec4 = false;
+    if (tree) {
+        static const int fb = std::getenv("SYMMICP_FUSED_BLOCKS") ? std::atoi(std::getenv("SYMMICP_FUSED_BLOCKS")) : 512;
+        const int tiles = (int)((c->n_loc + kPassThreads - 1) / kPassThreads);
+        blocks = tiles < fb ? tiles : fb;
+    } else {
+        vec4 = (c->n_loc % 4 == 0) && (c->n_t % 4 == 0) && (c->src_off % 4 == 0);
+        static const int id_cap = std::getenv("SYMMICP_ID_BLOCKS") ? std::atoi(std::getenv("SYMMICP_ID_BLOCKS")) : 2048;
+        const int nb = (int)(((vec4 ? c->n_loc / 4 : c->n_loc) + kPassThreads - 1) / kPassThreads);
+        blocks = nb < id_cap ? (nb > 0 ? nb : 1) : id_cap;
+    }
+    c->pass_blocks = blocks;
+    uint32_t *counters = tree ? c->wl_count : nullptr;
+    // the record of the last complete pass is in d_sums: solve from it, then `want` x (pass, reduce, [all-reduce,] solve)
+    launch_reduce_solve(c->partials, blocks, c->d_sums, 2, c->d_loop, lc, c->h_ring_dev, symmicp_ctx::kRing, counters, c->stream);
+    for (int p = 0; p < want; p++) {
+        hipEvent_t *ev = nullptr;
+        if (c->timing == 1) {
+            if (c->ev_used == symmicp_ctx::kEvRing) flush_events(c);
+            ev = c->ev + c->ev_used * symmicp_ctx::kEvPer;
+            c->ev_split[c->ev_used] = 1;
+            hipEventRecord(ev[0], c->stream);
+        }
+        if (tree) launch_pass_fused(a, c->ix, c->wl, blocks, c->stream);
+        else launch_pass_identity(a, c->tgt, blocks, vec4, c->stream);
+        if (ev) { hipEventRecord(ev[4], c->stream); c->ev_used++; }
+        if (c->comm || blocks > 512) {
+            // sharded: the record is summed over the ranks before the solve; many partial records (an 8M-point identity pass):
+            // the 40-block reduce is faster than one block's
+            launch_final_reduce(c->partials, blocks, c->d_sums, nullptr, c->ticket, 0ull, counters, 0, c->stream);
+            if (c->comm) {
+                int r = g_rccl.AllReduce(c->d_sums, c->d_sums, kNSum, kNcclFloat64, kNcclSum, c->comm, c->stream);
+                if (r != 0) return fail(c, SYMMICP_ERR_COMM, std::string("ncclAllReduce: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?"));
+            }
+            launch_reduce_solve(c->partials, blocks, c->d_sums, 1, c->d_loop, lc, c->h_ring_dev, symmicp_ctx::kRing, counters, c->stream);
+        } else {
+            launch_reduce_solve(c->partials, blocks, c->d_sums, 0, c->d_loop, lc, c->h_ring_dev, symmicp_ctx::kRing, counters, c->stream);
+        }
+    }
+    const unsigned long long seq = ++c->batch_seq;
+    launch_loop_end(c->d_loop, c->h_loop_dev, c->h_done_dev, seq, c->stream);
+    volatile unsigned long long *flag = reinterpret_cast<volatile unsigned long long *>(c->h_done);
+    const double t_spin = now_s();
+    unsigned spins = 0;
+    bool got = false;
+    while (!(got = (*flag == seq))) {
+        __builtin_ia32_pause();
+        if ((++spins & 0xFFFu) == 0) {
+            if (hipStreamQuery(c->stream) != hipErrorNotReady) { got = (*flag == seq); break; }
+            if (now_s() - t_spin > 60.0) break;
+        }
+    }
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    if (!got) {
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        HIP_TRY(c, hipGetLastError());
+        if (*flag != seq) return fail(c, SYMMICP_ERR_HIP, "batch finished without publishing its end flag");
+    }
+    const LoopState &hl = *c->h_loop;
+    const int it1 = hl.iters;                         // passes complete
+    if (it1 < it0 || it1 > it0 + want) return fail(c, SYMMICP_ERR_HIP, "device loop state out of range");
+    // the diffs the reference prints before iterations it0+1 .. it1 (+1 when the loop went on into a pass that was not completed)
+    for (int k = it0; k < it1; k++) diffs_before[k - it0] = (k == it0) ? (float)c->last.s[33] : (float)c->h_ring[k % symmicp_ctx::kRing].sums[33];
+    if (it1 > it0) {
+        std::memcpy(c->last.s, c->h_ring[it1 % symmicp_ctx::kRing].sums, sizeof(double) * kNSum);
+        std::memcpy(c->X, c->h_ring[(it1 - 1) % symmicp_ctx::kRing].X, sizeof(float) * 16);      // transform the last complete pass applied
+        c->st.passes += it1 - it0;
+    }
+    (void)X0;
+    c->iters = it1;
+    c->last_list_len = tree ? 0 : -1;
+    *n_done = it1 - it0;
+    *small_step = hl.reason == LOOP_DONE && hl.small_step != 0;
+    if (tree && it1 > it0) c->last_uncertified = c->h_ring[it1 % symmicp_ctx::kRing].pad;
+    if (std::getenv("SYMMICP_DEBUG_HOST")) std::fprintf(stderr, "[symmicp host] batch: %d of %d passes on the device, reason %d\n", it1 - it0, want, hl.reason);
+    if (hl.reason == LOOP_SLOW) c->host_passes_since_bailout = 1;      // one host pass, then look again
+    if (hl.reason == LOOP_REDO_PASS || hl.reason == LOOP_HOST_SOLVE) {
+        c->host_passes_since_bailout = 0;
+        c->last_list_len = -1;                        // the host's next pass runs the full search
+        c->st.kernel_launches[7]++;                   // counted with the repairs
+    }
     return SYMMICP_OK;
 }
 
@@ -1082,11 +1249,32 @@ int symmicp_align(symmicp_ctx *c, const float *guess16, symmicp_result *out)
     float diff = it.diff;                                           // myicp.cpp:122
     out->diff_initial = diff;
     int iters = 0;
-    while ((c->cfg.fixed_iters || diff > c->cfg.diff_threshold) && iters++ < c->cfg.max_iters) {   // myicp.cpp:123
+    // myicp.cpp:123: while (diff > diff_threshold && iters++ < max_iters)
+    while ((c->cfg.fixed_iters || diff > c->cfg.diff_threshold) && iters < c->cfg.max_iters) {
+        if (batch_eligible(c)) {
+            // the same loop, run by the device for the iterations that are left (run_batch); afterwards this loop goes on from the
+            // last complete pass -- and ends by its own test where the device loop ended by the same test
+            float db[symmicp_ctx::kRing];
+            int done = 0;
+            bool small = false;
+            st = run_batch(c, c->cfg.max_iters - iters, db, &done, &small);
+            if (st != SYMMICP_OK) break;
+            for (int k = 0; k < done; k++) {
+                iters++;
+                if (c->cfg.verbose) std::printf("iters#%d\ndiff: %g\n", iters, db[k]);
+                if (iters <= 64) out->diffs[iters - 1] = db[k];
+            }
+            diff = (float)c->last.s[33];
+            if (small) break;
+            if (done > 0 || c->host_passes_since_bailout == 0) continue;
+            // (the device did nothing and asked for nothing: take one step here)
+        }
+        iters++;
         if (c->cfg.verbose) std::printf("iters#%d\ndiff: %g\n", iters, diff);                       // myicp.cpp:125-126
         if (iters <= 64) out->diffs[iters - 1] = diff;
         st = symmicp_step(c, &it);
         if (st != SYMMICP_OK) { iters--; break; }
+        c->host_passes_since_bailout++;
         diff = it.diff;                                             // myicp.cpp:141
         if (c->cfg.eps_rotation > 0.f && c->cfg.eps_translation > 0.f && !c->cfg.fixed_iters) {
             // convergence on the increment (the reference only has the diff threshold, myicp.cpp:123)
@@ -1097,7 +1285,6 @@ int symmicp_align(symmicp_ctx *c, const float *guess16, symmicp_result *out)
             if (ang < c->cfg.eps_rotation && tn < c->cfg.eps_translation) break;
         }
     }
-    if (iters > c->cfg.max_iters) iters = c->cfg.max_iters;
     out->status = st;
     out->iters = iters;
     out->diff_final = diff;

@@ -18,6 +18,7 @@
 #include "symmicp_internal.h"
 #include "device_common.h"
 #include "oct_walk.h"
+#include "solve_core.h"
 #pragma clang fp contract(off)
 
 namespace symmicp {
@@ -132,8 +133,11 @@ __device__ __forceinline__ void acc_block_reduce_store(Acc &a, double *partials,
 // arrays (needs n, the target offset and the array lengths to be multiples of 4 so every column stays
 // 16-byte aligned); VEC = 1 is the general form.
 template <int VEC>
-__global__ __launch_bounds__(kPassThreads) void k_pass_identity(PassArgs a, CloudSoA tgt)
+__global__ __launch_bounds__(kPassThreads) void k_pass_identity(PassArgs a_in, CloudSoA tgt)
 {
+    if (a_in.loop && a_in.loop->stop) return;
+    PassArgs a = a_in;
+    if (a_in.loop) a.X = a_in.loop->Xapply;        // device-driven loop: the transform k_reduce_solve left behind
     Acc acc; acc_zero(acc);
     const uint32_t stride = gridDim.x * blockDim.x * VEC;
     for (uint32_t i0 = (blockIdx.x * blockDim.x + threadIdx.x) * VEC; i0 < a.n; i0 += stride) {
@@ -306,7 +310,10 @@ __device__ __forceinline__ float axis_gap2(float p, float origin, int c, float h
 // ---------------------------------------------------------------------------
 constexpr float kSlackFrac = 0.25f;
 
-__global__ __launch_bounds__(kPassThreads) void k_search_cells(PassArgs a, TargetIndex ix, WorkLists wl)
+// One tile of 256 queries (i >= a.n: idle lane).  Called by k_search_cells (tile = block) and by k_pass_fused (the queries its
+// streaming phase could not certify).
+__device__ __forceinline__ void cells_tile(const PassArgs &a, const TargetIndex &ix, const WorkLists &wl, const Affine &X, const uint32_t i,
+                                           const uint32_t shard, const bool count_uncertified)
 {
     __shared__ float s_px[kPassThreads], s_py[kPassThreads], s_pz[kPassThreads];
     __shared__ unsigned long long s_key[kPassThreads];
@@ -318,8 +325,6 @@ __global__ __launch_bounds__(kPassThreads) void k_search_cells(PassArgs a, Targe
     __shared__ uint32_t s_anyw[kPassThreads / 64];     // per-wave flags for block-wide "any" votes
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint32_t shard = blockIdx.x & (kShards - 1);
-    const uint32_t i = xcd_remap(blockIdx.x, gridDim.x) * kPassThreads + tid;
     const bool active = i < a.n;
     const float inf = __int_as_float(0x7f800000);
 
@@ -329,7 +334,7 @@ __global__ __launch_bounds__(kPassThreads) void k_search_cells(PassArgs a, Targe
     b.d2 = inf; b.pos = -1; b.row = 0x7fffffff;
     uint32_t mask = 0;                 // cells of this query to scan this round, bit = kx + 3*ky + 9*kz
     uint32_t mask_rest = 0;            // probe: the other cells of the 3x3x3 block, scanned only if the 2x2x2 block cannot prove its best
-    bool defer = false, searched = false, probe = false;
+    bool defer = false, searched = false, probe = false, uncert = false;
     float lim = 0.f, lim_full = 0.f;   // everything outside the scanned cells is at least this far from the query
     if (active) {
         // Two memory round trips decide a certified pair: everything addressed by i first (the certificate is loaded
@@ -338,7 +343,7 @@ __global__ __launch_bounds__(kPassThreads) void k_search_cells(PassArgs a, Targe
         const int32_t prev = a.pos_prev ? a.pos_prev[i] : -1;
         float clear = 0.0f, rx = 0.0f, ry = 0.0f, rz = 0.0f;                              // L (0: no certificate), p_ref
         if (a.use_slack) { const float4 ce = a.cert[i]; rx = ce.x; ry = ce.y; rz = ce.z; clear = ce.w; }      // one 16-byte load
-        px = xf_row(a.X.m + 0, x, y, z, 1.0f); py = xf_row(a.X.m + 4, x, y, z, 1.0f); pz = xf_row(a.X.m + 8, x, y, z, 1.0f);
+        px = xf_row(X.m + 0, x, y, z, 1.0f); py = xf_row(X.m + 4, x, y, z, 1.0f); pz = xf_row(X.m + 8, x, y, z, 1.0f);
         if (prev >= 0 && (uint32_t)prev < ix.n) {
             const float4 q = ix.tq[prev];
             const float d2 = dist2(px, py, pz, q.x, q.y, q.z);
@@ -353,6 +358,7 @@ __global__ __launch_bounds__(kPassThreads) void k_search_cells(PassArgs a, Targe
         if (certified) {
             a.d2_out[i] = b.d2;          // same pair, refreshed distance; position, certificate unchanged
         } else {
+            uncert = true;
             defer = true;
             if (b.pos >= 0 && ix.glevel > 0) {
                 const float margin = 2e-3f * ix.h;
@@ -449,6 +455,12 @@ __global__ __launch_bounds__(kPassThreads) void k_search_cells(PassArgs a, Targe
                 sl_push(wl.work, shard, i);
             }
         }
+    }
+    if (count_uncertified) {
+        // how many pairs had to be searched this pass: tells the host when the alignment has converged far enough for the fused
+        // pass (engine.cpp, batch_eligible); word 1 of the work list's counter block is free (counters sit 16 words apart)
+        const unsigned long long mu = __ballot(uncert);
+        if (lane == 0 && mu) atomicAdd(wl.work.counts + 1, (uint32_t)__popcll(mu));
     }
     s_px[tid] = px; s_py[tid] = py; s_pz[tid] = pz;
     s_pos[tid] = b.pos;
@@ -596,6 +608,102 @@ __global__ __launch_bounds__(kPassThreads) void k_search_cells(PassArgs a, Targe
             store_pair_record(a, ix, i, s_pos[tid]);
         }
     }
+}
+
+__global__ __launch_bounds__(kPassThreads) void k_search_cells(PassArgs a, TargetIndex ix, WorkLists wl)
+{
+    cells_tile(a, ix, wl, a.X, xcd_remap(blockIdx.x, gridDim.x) * kPassThreads + threadIdx.x, blockIdx.x & (kShards - 1), true);
+}
+
+// ---------------------------------------------------------------------------
+// k_pass_fused: the whole pass of a CONVERGED alignment in one kernel.  Once ICP has converged nearly every pair is
+// certified, so the pass is a stream: per point 12 B position + 12 B normal + the pair's own 32-byte record copy + the
+// 16-byte certificate, all coalesced; certified pairs are accumulated on the spot (rows of func.cpp:51-58, 37 fp64 sums).
+// Separate search and accumulate kernels read the source twice and cost two launches.
+//   stream   grid-stride over tiles of 256 points: certificate test (the expressions of cells_tile, phase 1); a pair that
+//            fails it goes to a list in LDS
+//   scan     the listed queries run through cells_tile, 256 at a time: exact scan, new pair, certificate and record copy
+//   settle   the listed queries once more: those that now have a pair are accumulated from their fresh record copy
+// A query the scan has to hand to the tree walk is appended to the work list and NOT accumulated (its record copy is
+// marked stale): the pass's record then reports a non-empty list and whoever drives the loop repeats the pass through
+// the separate kernels.  So does a block whose LDS list overflows (the early passes of an alignment: they keep the
+// separate kernels).  The transform comes from the device-resident loop state when there is one (a.loop): passes can be
+// enqueued back to back without the host (k_reduce_solve writes the next transform); a stopped loop returns at once.
+// ---------------------------------------------------------------------------
+constexpr int kFusedList = 1024;
+
+__device__ __forceinline__ void fused_accumulate(Acc &acc, const PassArgs &a, const Affine &X, float nx, float ny, float nz, float px, float py, float pz,
+                                                 const float4 &q, const float4 &nq, float d2)
+{
+    const float npx = xf_row(X.m + 0, nx, ny, nz, X.nrm_w), npy = xf_row(X.m + 4, nx, ny, nz, X.nrm_w), npz = xf_row(X.m + 8, nx, ny, nz, X.nrm_w);
+    if (a.max_d2 > 0.0f && d2 > a.max_d2) return;
+    if (a.min_ndot > -1.0f && (npx * nq.x + npy * nq.y) + npz * nq.z < a.min_ndot) return;
+    acc_pair(acc, px, py, pz, npx, npy, npz, q.x, q.y, q.z, nq.x, nq.y, nq.z, d2, a.pivot, a.p2p);
+}
+
+#ifndef FUSED_WAVES
+#define FUSED_WAVES 2
+#endif
+__global__ __launch_bounds__(kPassThreads, FUSED_WAVES) void k_pass_fused(PassArgs a, TargetIndex ix, WorkLists wl)
+{
+    if (a.loop && a.loop->stop) return;
+    __shared__ uint32_t s_list[kFusedList];
+    __shared__ uint32_t s_cnt;
+    const Affine X = a.loop ? a.loop->Xapply : a.X;
+    Acc acc; acc_zero(acc);
+    if (threadIdx.x == 0) s_cnt = 0;
+    __syncthreads();
+    const uint32_t tiles = (a.n + kPassThreads - 1) / kPassThreads;
+    const uint32_t tiles_p = ((tiles + 7u) / 8u) * 8u;
+    // ---- stream (tile numbers are dealt so that each XCD works on one contiguous part of the sorted source)
+    for (uint32_t t = blockIdx.x; t < tiles_p; t += gridDim.x) {
+        const uint32_t i = xcd_remap(t, tiles_p) * kPassThreads + threadIdx.x;
+        if (i >= a.n) continue;
+        // one round trip: everything the common case (certified pair) needs
+        const float x = a.in.x[i], y = a.in.y[i], z = a.in.z[i];
+        const float nx = a.in.nx[i], ny = a.in.ny[i], nz = a.in.nz[i];
+        const float4 q = a.pairrec[2 * (size_t)i], nq = a.pairrec[2 * (size_t)i + 1];
+        const float4 ce = a.cert[i];
+        const float px = xf_row(X.m + 0, x, y, z, 1.0f), py = xf_row(X.m + 4, x, y, z, 1.0f), pz = xf_row(X.m + 8, x, y, z, 1.0f);
+        bool certified = false;
+        float d2 = 0.0f;
+        if (nq.w == 0.0f) {                                    // a fresh copy of the previous winner (same bits as tq[prev])
+            d2 = dist2(px, py, pz, q.x, q.y, q.z);
+            const float m2 = dist2(px, py, pz, ce.x, ce.y, ce.z);
+            certified = (__builtin_amdgcn_sqrtf(d2) + __builtin_amdgcn_sqrtf(m2)) * 1.000002f < ce.w;          // cells_tile, phase 1
+        }
+        if (certified) {
+            a.d2_out[i] = d2;                                  // same pair, refreshed distance
+            fused_accumulate(acc, a, X, nx, ny, nz, px, py, pz, q, nq, d2);
+        } else {
+            const uint32_t k = atomicAdd(&s_cnt, 1u);
+            if (k < (uint32_t)kFusedList) s_list[k] = i;
+            else { a.pairrec[2 * (size_t)i + 1].w = 2.0f; sl_push(wl.work, blockIdx.x & (kShards - 1), i); }      // overflow: the pass will be repeated
+        }
+    }
+    __syncthreads();
+    const uint32_t cnt = min(s_cnt, (uint32_t)kFusedList);
+    if (threadIdx.x == 0 && s_cnt) atomicAdd(wl.work.counts + 1, s_cnt);          // pairs that had to be searched (see cells_tile)
+    // ---- scan
+    for (uint32_t base = 0; base < cnt; base += kPassThreads) {
+        const uint32_t e = base + threadIdx.x;
+        cells_tile(a, ix, wl, X, e < cnt ? s_list[e] : 0xFFFFFFFFu, blockIdx.x & (kShards - 1), false);
+        __syncthreads();
+    }
+    // ---- settle (each thread meets the entries it scanned itself)
+    for (uint32_t base = 0; base < cnt; base += kPassThreads) {
+        const uint32_t e = base + threadIdx.x;
+        if (e >= cnt) continue;
+        const uint32_t i = s_list[e];
+        const float4 q = a.pairrec[2 * (size_t)i], nq = a.pairrec[2 * (size_t)i + 1];
+        if (nq.w != 0.0f) continue;                            // no target at all, or handed to the walk
+        const float x = a.in.x[i], y = a.in.y[i], z = a.in.z[i];
+        const float nx = a.in.nx[i], ny = a.in.ny[i], nz = a.in.nz[i];
+        const float px = xf_row(X.m + 0, x, y, z, 1.0f), py = xf_row(X.m + 4, x, y, z, 1.0f), pz = xf_row(X.m + 8, x, y, z, 1.0f);
+        fused_accumulate(acc, a, X, nx, ny, nz, px, py, pz, q, nq, dist2(px, py, pz, q.x, q.y, q.z));
+    }
+    __syncthreads();
+    acc_block_reduce_store(acc, a.partials, gridDim.x);
 }
 
 // ---------------------------------------------------------------------------
@@ -875,6 +983,11 @@ __global__ __launch_bounds__(256) void k_final_reduce(const double *__restrict__
                     s_len = v;
                     out_dev[kNSum - 1] = (double)v;
                     if (out_host) out_host[kNSum - 1] = (double)v;
+                    // pairs searched this pass (cells_tile): travels in the slot before, cleared for the next pass
+                    const double u = (double)counters_to_clear[1];
+                    out_dev[kNSum - 2] = u;
+                    if (out_host) out_host[kNSum - 2] = u;
+                    counters_to_clear[1] = 0;
                 }
             }
             __syncthreads();
@@ -888,6 +1001,127 @@ __global__ __launch_bounds__(256) void k_final_reduce(const double *__restrict__
                 reinterpret_cast<volatile unsigned long long *>(out_host)[kNSum] = seq;
             }
         }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// k_reduce_solve: the end of one pass and the start of the next WITHOUT the host (device-driven runs of passes).
+//   reduce   partials[40][nblocks] -> the pass's record (one 512-thread block: wave w sums rows w, w+8, ...; fixed order).
+//            Sharded runs reduce with k_final_reduce, all-reduce the record over the ranks and call this kernel with
+//            REDUCE = false: the record is then read from out_dev.
+//   check    a non-empty work list means the fused pass left queries to the tree walk: the pass has to be redone through
+//            the separate kernels (LOOP_REDO_PASS, the host takes over)
+//   loop     the reference's test `diff > threshold && iters++ < max_iters` (myicp.cpp:123) on the record's slot 33
+//   solve    estimateTransformSymm (func.cpp:76-102) from the record: the SAME source as the host solve (solve_core.h),
+//            run by one thread, with the pivot-ratio conditioning estimate; anything but a clean solve is handed back to
+//            the host's exact form (LOOP_HOST_SOLVE).  transform = increment * transform (myicp.cpp:138); the next pass
+//            reads it from the loop state.
+// Every pass leaves a LoopRecord in host-mapped memory (sums, increment, transform); the host reads them after the batch.
+// ---------------------------------------------------------------------------
+template <bool REDUCE>
+__global__ __launch_bounds__(512) void k_reduce_solve(const double *__restrict__ partials, int nblocks, double *out_dev, int solve_only, LoopState *loop,
+                                                       LoopConfig cfg, LoopRecord *ring, int ring_len, uint32_t *counters_to_clear)
+{
+    if (loop->stop) return;
+    __shared__ double s_sum[kNSum];
+    __shared__ uint32_t s_len, s_unc;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    if (t == 0) { s_len = 0; s_unc = 0; }
+    if (!solve_only) {
+        if (REDUCE) {
+            // wave w sums rows w, w + 8, ... (5 rows); all of a wave's loads are issued before the first sum (the partials sit in
+            // L2 / HBM behind a kernel boundary: dependent round trips, not bytes, are what this block would wait for)
+            double v[5];
+#pragma unroll
+            for (int r = 0; r < 5; r++) {
+                const double *row = partials + (size_t)(wave + 8 * r) * nblocks;
+                double acc0 = 0.0;
+                if (nblocks <= 512) {
+                    double c[8];
+#pragma unroll
+                    for (int j = 0; j < 8; j++) c[j] = (lane + 64 * j < nblocks) ? row[lane + 64 * j] : 0.0;
+#pragma unroll
+                    for (int j = 0; j < 8; j++) acc0 += c[j];
+                } else {
+                    for (int j = lane; j < nblocks; j += 64) acc0 += row[j];
+                }
+                v[r] = acc0;
+            }
+#pragma unroll
+            for (int r = 0; r < 5; r++) {
+                const double x = wave_sum_to_lane63(v[r]);
+                const int k = wave + 8 * r;
+                if (lane == 63) s_sum[k] = (k < kNAcc) ? x : 0.0;
+            }
+        } else if (t < kNSum) s_sum[t] = out_dev[t];
+        __syncthreads();
+        if (counters_to_clear) {
+            if (REDUCE && t < 64) {
+                uint32_t v = counters_to_clear[t * kShardStride];                  // the work list's shards
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) v += (uint32_t)__shfl_xor((int)v, off, 64);
+                if (t == 0) s_len = v;
+            }
+            if (!REDUCE && t == 0) s_len = (uint32_t)s_sum[kNSum - 1];             // summed over the ranks by the all-reduce
+            __syncthreads();
+            if (t == 0) { s_unc = REDUCE ? counters_to_clear[1] : (uint32_t)s_sum[kNSum - 2]; if (REDUCE) counters_to_clear[1] = 0; }
+            if (REDUCE) for (int c = t; c < 2 * kShards; c += 512) counters_to_clear[c * kShardStride] = 0;
+        }
+    } else {
+        if (t < kNSum) s_sum[t] = out_dev[t];
+    }
+    __syncthreads();
+    if (t != 0) return;
+    int it = loop->iters;
+    if (!solve_only) {
+        if (cfg.tree && s_len > 0u) { loop->stop = 1; loop->reason = LOOP_REDO_PASS; return; }
+        it += 1;                                                        // this pass is complete
+        loop->iters = it;
+        LoopRecord &r = ring[it % ring_len];
+        for (int k = 0; k < kNSum; k++) { const double v = (k >= kNAcc) ? 0.0 : s_sum[k]; r.sums[k] = v; if (REDUCE) out_dev[k] = v; }
+        r.solved = 0;
+        r.pad = (int32_t)s_unc;
+        // many pairs had to be searched again (the cloud moved): the separate kernels do that faster; this pass is complete
+        if (cfg.tree && s_unc > cfg.uncertified_limit) { loop->stop = 1; loop->reason = LOOP_SLOW; return; }
+    }
+    // ---- myicp.cpp:123
+    const float diff = (float)s_sum[33];
+    if (loop->small_step || !((cfg.fixed_iters || diff > cfg.diff_threshold) && it < cfg.max_iters)) {
+        loop->stop = 1; loop->reason = LOOP_DONE;
+        return;
+    }
+    // ---- func.cpp:76-102
+    symmicp_sums S;
+    for (int k = 0; k < kNSum; k++) S.s[k] = (k >= kNAcc) ? 0.0 : s_sum[k];
+    float pbar[3], qbar[3], av[3], tv[3], rc = 0.f, Xi[16];
+    const int st = (cfg.mode == SYMMICP_MODE_QUIRKS) ? solve::solve_quirks(S, pbar, qbar, av, tv, &rc, Xi, false)
+                                                      : solve::solve_paper(S, cfg.pivot, pbar, qbar, av, tv, &rc, Xi, false);
+    if (st != SYMMICP_OK || !(rc > 1e-6f)) { loop->stop = 1; loop->reason = LOOP_HOST_SOLVE; return; }
+    float Xn[16];
+    solve::mat4_mul(Xi, loop->X, Xn);                                   // myicp.cpp:138
+    for (int k = 0; k < 16; k++) loop->X[k] = Xn[k];
+    const float *ap = cfg.incremental ? Xi : Xn;
+    for (int k = 0; k < 12; k++) loop->Xapply.m[k] = ap[k];
+    loop->Xapply.nrm_w = cfg.nrm_w;
+    LoopRecord &r = ring[it % ring_len];
+    for (int k = 0; k < 16; k++) { r.increment[k] = Xi[k]; r.X[k] = Xn[k]; }
+    r.rcond = rc; r.status = st; r.solved = 1;
+    if (cfg.eps_rotation > 0.f && cfg.eps_translation > 0.f && !cfg.fixed_iters) {
+        // convergence on the increment (engine.cpp, symmicp_align): the pass that applies this increment still runs
+        const double tr = ((double)Xi[0] + Xi[5] + Xi[10] - 1.0) * 0.5;
+        const double ang = acos(tr > 1.0 ? 1.0 : (tr < -1.0 ? -1.0 : tr));
+        const double tn = sqrt((double)Xi[3] * Xi[3] + (double)Xi[7] * Xi[7] + (double)Xi[11] * Xi[11]);
+        if (ang < cfg.eps_rotation && tn < cfg.eps_translation) loop->small_step = 1;
+    }
+}
+
+// last kernel of a batch: copy the loop state where the host can read it and publish the batch's sequence number
+__global__ __launch_bounds__(64) void k_loop_end(const LoopState *loop, LoopState *host_copy, unsigned long long *done_flag, unsigned long long seq)
+{
+    if (threadIdx.x == 0) {
+        *host_copy = *loop;
+        __threadfence_system();
+        *reinterpret_cast<volatile unsigned long long *>(done_flag) = seq;
     }
 }
 
@@ -1049,6 +1283,24 @@ void launch_final_reduce(const double *partials, int blocks, double *out_dev, do
 {
     hipLaunchKernelGGL(k_final_reduce, dim3(kNSum), dim3(256), 0, s, partials, blocks, out_dev, out_host_mapped, ticket, seq,
                        counters_to_clear, keep_nonempty);
+}
+
+void launch_pass_fused(const PassArgs &a, const TargetIndex &ix, const WorkLists &wl, int blocks, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_pass_fused, dim3(blocks), dim3(kPassThreads), 0, s, a, ix, wl);
+}
+
+void launch_reduce_solve(const double *partials, int blocks, double *out_dev, int mode, LoopState *loop, LoopConfig cfg, LoopRecord *ring, int ring_len,
+                         uint32_t *counters_to_clear, hipStream_t s)
+{
+    // mode 0: reduce + check + solve (single GPU); 1: record already in out_dev (after the all-reduce); 2: solve only (start of a batch)
+    if (mode == 0) hipLaunchKernelGGL(k_reduce_solve<true>, dim3(1), dim3(512), 0, s, partials, blocks, out_dev, 0, loop, cfg, ring, ring_len, counters_to_clear);
+    else hipLaunchKernelGGL(k_reduce_solve<false>, dim3(1), dim3(512), 0, s, partials, blocks, out_dev, mode == 2 ? 1 : 0, loop, cfg, ring, ring_len, counters_to_clear);
+}
+
+void launch_loop_end(const LoopState *loop, LoopState *host_copy, unsigned long long *done_flag, unsigned long long seq, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_loop_end, dim3(1), dim3(64), 0, s, loop, host_copy, done_flag, seq);
 }
 
 void launch_publish(const double *sums_dev, double *out_host_mapped, unsigned long long seq, hipStream_t s)

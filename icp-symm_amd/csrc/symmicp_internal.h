@@ -82,6 +82,32 @@ struct WorkLists {
     ShardList retry;                      // queries the budgeted thread-per-query walk gave up on
 };                                        // the two counter blocks are contiguous and cleared by the final reduce
 
+// Device-resident state of a device-driven run of passes (symmicp_align's batches): written by k_reduce_solve, read by the
+// pass kernels.  Lives in device memory; `ring` entries live in host-mapped memory and are read by the host afterwards.
+struct LoopState {
+    float X[16];             // cumulative transform (myicp.cpp:138)
+    Affine Xapply;           // what the next pass applies to its input (cumulative apply: X; incremental: the last increment)
+    int32_t stop;            // != 0: every kernel of the batch returns at once
+    int32_t reason;          // LOOP_* below
+    int32_t iters;           // passes of this alignment completed so far (the reference's `iters`)
+    int32_t small_step;      // the last increment was below eps_rotation / eps_translation: stop after the pass that applies it
+};
+enum { LOOP_RUNNING = 0, LOOP_DONE = 1, LOOP_REDO_PASS = 2, LOOP_HOST_SOLVE = 3, LOOP_SLOW = 4 };
+struct LoopConfig {
+    int32_t mode, fixed_iters, max_iters, incremental, tree;
+    float diff_threshold, eps_rotation, eps_translation, nrm_w;
+    float pivot[3];
+    uint32_t uncertified_limit;   // TREE: more pairs than this searched in a pass -> back to the separate kernels (LOOP_SLOW)
+};
+struct LoopRecord {          // one per pass, host-mapped
+    double sums[SYMMICP_NSUM];       // the pass's record (after the exchange over ranks)
+    float increment[16], X[16];      // the increment solved FROM this record and the cumulative transform after it
+    float rcond;
+    int32_t status;                  // status of that solve
+    int32_t solved;                  // 1: increment / X are valid (the loop went on)
+    int32_t pad;                     // (pairs searched in this pass)
+};
+
 struct PassArgs {
     // source share (planar).  `in` is read; if writeback, `out` receives the transformed points/normals
     CloudSoA in, out;
@@ -106,6 +132,7 @@ struct PassArgs {
     int32_t refresh_records;            // k_accumulate may replace stale copies (0 in a pass that may still be repaired)
     float4 *cert;                       // per pair: (ref.xyz, clear radius L around ref; L = 0: no certificate)
     int32_t use_slack;                  // 0 on the first pass of an alignment (certificates not valid yet)
+    const LoopState *loop;              // device-driven loop: the transform comes from here (null: from X above)
 };
 
 // ---- kernel launchers (kernels.hip) ---------------------------------------
@@ -122,6 +149,12 @@ uint32_t shard_capacity(uint32_t n_points);
 // keep_nonempty: leave the append-list counters alone when the work list is not empty (stage-1 passes)
 void launch_final_reduce(const double *partials, int blocks, double *out_dev, double *out_host_mapped, uint32_t *ticket,
                          unsigned long long seq, uint32_t *counters_to_clear, int keep_nonempty, hipStream_t s);
+// fused pass of a converged alignment (k_pass_fused) and the device-side end of a pass (k_reduce_solve): see kernels_pass.hip
+void launch_pass_fused(const PassArgs &a, const TargetIndex &ix, const WorkLists &wl, int blocks, hipStream_t s);
+// mode 0: reduce + check + solve (single GPU); 1: the record is already in out_dev (after the all-reduce); 2: solve only (start of a batch)
+void launch_reduce_solve(const double *partials, int blocks, double *out_dev, int mode, LoopState *loop, LoopConfig cfg, LoopRecord *ring, int ring_len,
+                         uint32_t *counters_to_clear, hipStream_t s);
+void launch_loop_end(const LoopState *loop, LoopState *host_copy, unsigned long long *done_flag, unsigned long long seq, hipStream_t s);
 void launch_publish(const double *sums_dev, double *out_host_mapped, unsigned long long seq, hipStream_t s);
 void launch_nn_brute(const CloudSoA &src, uint32_t n_s, const Affine &X, const float4 *tq, uint32_t n_t,
                      unsigned long long *best64, hipStream_t s);

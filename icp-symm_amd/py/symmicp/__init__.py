@@ -39,7 +39,7 @@ class Config(C.Structure):
                 ("apply", C.c_int32), ("max_iters", C.c_int32), ("diff_threshold", C.c_float),
                 ("max_corr_dist", C.c_float), ("fixed_iters", C.c_int32), ("sort_source", C.c_int32),
                 ("verbose", C.c_int32), ("min_normal_dot", C.c_float), ("eps_rotation", C.c_float),
-                ("eps_translation", C.c_float), ("reserved", C.c_int32 * 2)]
+                ("eps_translation", C.c_float), ("host_loop", C.c_int32), ("reserved", C.c_int32 * 1)]
 
 
 class Sums(C.Structure):

@@ -83,7 +83,8 @@ typedef struct {
     float min_normal_dot;      /* > -1: drop pairs whose (transformed) source normal . target normal is below this */
     float eps_rotation;        /* > 0 (radians) together with eps_translation > 0: also stop once an increment */
     float eps_translation;     /*   rotates by less than eps_rotation and translates by less than eps_translation */
-    int32_t reserved[2];
+    int32_t host_loop;         /* != 0: symmicp_align never hands runs of iterations to the device (every solve on the host, as symmicp_step does) */
+    int32_t reserved[1];
 } symmicp_config;
 
 /* One reduction record = everything the host needs from one pass over the
