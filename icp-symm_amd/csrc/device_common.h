@@ -31,10 +31,14 @@ __device__ __forceinline__ float boxdist2(float px, float py, float pz, const fl
     return (dx * dx + dy * dy) + dz * dz;
 }
 
+// A shard's capacity covers every producer -> shard mapping the kernels use (shard_capacity); an append beyond it would run
+// into the next shard, so it is dropped and counted instead (word 2 of the list's counter block): the final reduce reports the
+// count and the host fails the pass rather than return pairs that were never searched.
 __device__ __forceinline__ void sl_push(const ShardList &L, uint32_t shard, uint32_t v)
 {
     const uint32_t k = atomicAdd(L.counts + shard * kShardStride, 1u);
-    L.items[(size_t)shard * L.cap + k] = v;
+    if (k < L.cap) L.items[(size_t)shard * L.cap + k] = v;
+    else atomicAdd(L.counts + 2, 1u);
 }
 
 // A list is consumed as the concatenation of its shards (balances consumers when shards are unevenly filled).
@@ -42,7 +46,7 @@ __device__ __forceinline__ void sl_push(const ShardList &L, uint32_t shard, uint
 __device__ __forceinline__ void sl_prefix(const ShardList &L, uint32_t *pre /* __shared__ [kShards + 1] */)
 {
     if (threadIdx.x < kShards) {
-        uint32_t v = L.counts[threadIdx.x * kShardStride];
+        uint32_t v = min(L.counts[threadIdx.x * kShardStride], L.cap);
 #pragma unroll
         for (int off = 1; off < kShards; off <<= 1) {
             const uint32_t u = __shfl_up(v, off, 64);

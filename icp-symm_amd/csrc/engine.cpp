@@ -172,6 +172,9 @@ struct symmicp_ctx {
     int ev_split[kEvRing] = {};      // 1 = split TREE pass (5 kernels), 0 = single pass kernel
     int ev_used = 0;
     symmicp_stats st{};
+    // host-side timing of the pass loop, printed by symmicp_destroy under SYMMICP_DEBUG_HOST
+    double t_launch = 0, t_spin = 0, t_between = 0, t_last_done = 0;
+    long n_pass_timed = 0;
 };
 
 // device buffer freed on every exit path.  alloc(): its own hipMalloc (release() hands the pointer to the context);
@@ -218,9 +221,6 @@ static void arena_begin(Arena &a, size_t want)
         }                                                                                                   \
     } while (0)
 
-// host-side timing of the pass loop, printed by symmicp_destroy under SYMMICP_DEBUG_HOST (debugging aid: process-wide, unsynchronised)
-static double g_t_launch = 0, g_t_spin = 0, g_t_between = 0, g_t_last_done = 0;
-static long g_n_pass = 0;
 
 static void shm_close(symmicp_ctx *c);
 
@@ -363,8 +363,8 @@ static void free_source(symmicp_ctx *c)
 void symmicp_destroy(symmicp_ctx *c)
 {
     if (!c) return;
-    if (std::getenv("SYMMICP_DEBUG_HOST") && g_n_pass)
-        std::fprintf(stderr, "[symmicp host] passes %ld: launch %.1f us, spin %.1f us, between passes %.1f us (per pass)\n", g_n_pass, 1e6 * g_t_launch / g_n_pass, 1e6 * g_t_spin / g_n_pass, 1e6 * g_t_between / g_n_pass);
+    if (std::getenv("SYMMICP_DEBUG_HOST") && c->n_pass_timed)
+        std::fprintf(stderr, "[symmicp host] passes %ld: launch %.1f us, spin %.1f us, between passes %.1f us (per pass)\n", c->n_pass_timed, 1e6 * c->t_launch / c->n_pass_timed, 1e6 * c->t_spin / c->n_pass_timed, 1e6 * c->t_between / c->n_pass_timed);
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
     if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
@@ -892,7 +892,7 @@ static int run_pass(symmicp_ctx *c, const float Xapply[16], bool from_cur, bool 
     if (blocks < 1) blocks = 1;
     c->pass_blocks = blocks;
     const double t_l0 = now_s();
-    if (g_t_last_done > 0) g_t_between += t_l0 - g_t_last_done;
+    if (c->t_last_done > 0) c->t_between += t_l0 - c->t_last_done;
     hipEvent_t *ev = nullptr;
     uint32_t walk_blocks = 0;
     bool optimistic = false;
@@ -927,6 +927,7 @@ static int run_pass(symmicp_ctx *c, const float Xapply[16], bool from_cur, bool 
             static const int acc_cap = std::getenv("SYMMICP_ACC_BLOCKS") ? std::atoi(std::getenv("SYMMICP_ACC_BLOCKS")) : 512;
             const int nb_all = (int)((c->n_loc + kPassThreads - 1) / kPassThreads);
             int ab = nb_all < acc_cap ? ((nb_all + 7) / 8) * 8 : acc_cap;
+            if (ab < 8) ab = 8;                     // (a rank whose share is empty still writes its zero record)
             c->pass_blocks = blocks = ab;
             // Walk grid: any size is correct (the kernel strides over the list); sized from the previous pass's list
             // length, which only shrinks while an alignment converges.  Unknown or long lists get the full grid.
@@ -952,7 +953,7 @@ static int run_pass(symmicp_ctx *c, const float Xapply[16], bool from_cur, bool 
         break;
     }
     if (ev && c->ev_split[c->ev_used] != 2) hipEventRecord(ev[4], c->stream);
-    g_t_launch += now_s() - t_l0;
+    c->t_launch += now_s() - t_l0;
     // Final reduce (+ all-reduce over ranks), then wait for the record.  It arrives in host-mapped memory followed by its
     // sequence number: spin on that word instead of paying a stream-synchronise wake-up per iteration.  A stuck stream
     // (kernel fault) is caught by the fallback.
@@ -979,7 +980,7 @@ static int run_pass(symmicp_ctx *c, const float Xapply[16], bool from_cur, bool 
             }
         }
         __atomic_thread_fence(__ATOMIC_ACQUIRE);
-        g_t_spin += now_s() - t_spin;
+        c->t_spin += now_s() - t_spin;
         if (!got) {
             HIP_TRY(c, hipStreamSynchronize(c->stream));
             HIP_TRY(c, hipGetLastError());
@@ -990,6 +991,8 @@ static int run_pass(symmicp_ctx *c, const float Xapply[16], bool from_cur, bool 
     if (int st = reduce_and_wait(optimistic ? 1 : 0)) return st;
     if (c->shm.slots) { if (int st = shm_exchange(c, c->h_sums)) return st; }
     // length of the work list (summed over ranks by the exchange, so every rank takes the same decision)
+    if (c->cfg.corr == SYMMICP_CORR_TREE && c->h_sums[kNSum - 3] != 0.0)
+        return fail(c, SYMMICP_ERR_HIP, "a work-list shard overflowed: appends were dropped (internal capacity error)");
     long long list_len = (c->cfg.corr == SYMMICP_CORR_TREE) ? (long long)c->h_sums[kNSum - 1] : -1;
     c->last_uncertified = (c->cfg.corr == SYMMICP_CORR_TREE && !first) ? (long long)c->h_sums[kNSum - 2] : -1;
     if (optimistic && list_len > 0) {
@@ -1001,7 +1004,7 @@ static int run_pass(symmicp_ctx *c, const float Xapply[16], bool from_cur, bool 
         if (c->shm.slots) { if (int st = shm_exchange(c, c->h_sums)) return st; }
     }
     if (ev) c->ev_used++;
-    g_t_last_done = now_s(); g_n_pass++;
+    c->t_last_done = now_s(); c->n_pass_timed++;
     if (c->ix.dbg) {
         unsigned long long h[8];
         hipMemcpy(h, c->ix.dbg, sizeof(h), hipMemcpyDeviceToHost);
@@ -1023,7 +1026,7 @@ static int run_pass(symmicp_ctx *c, const float Xapply[16], bool from_cur, bool 
                      (long long)c->st.passes, h[1], h[2], h[6], h[7], h[0], h[3], list_len, h[4], h[5]);
     }
     std::memcpy(c->last.s, c->h_sums, sizeof(double) * kNSum);
-    if (c->cfg.corr == SYMMICP_CORR_TREE) c->last.s[kNSum - 1] = c->last.s[kNSum - 2] = 0.0;      // those slots carried the list length and the number of searched pairs, not sums
+    if (c->cfg.corr == SYMMICP_CORR_TREE) c->last.s[kNSum - 1] = c->last.s[kNSum - 2] = c->last.s[kNSum - 3] = 0.0;      // those slots carried the list length and the number of searched pairs, not sums
     c->last_list_len = list_len;
     c->st.passes++;
     return SYMMICP_OK;
@@ -1390,6 +1393,63 @@ int symmicp_solve(int mode, const symmicp_sums *sums, const float pivot[3], floa
 }
 
 // ---- normals pre-step (MyICP::estimateNormals, myicp.cpp:152-172) --------------------------------
+// Runs on a context the caller owns (its stream and arenas are reused: a tracker that estimates normals per scan pays no
+// context set-up); the context's target and source stay as they are -- what the estimate allocates behind the target's arrays
+// in the keep-arena is released again.
+int symmicp_ctx_estimate_normals(symmicp_ctx *c, const float *xyz, size_t row_stride, size_t col_stride, size_t n, int k,
+                                 const float viewpoint[3], float *nrm_out, float *curv_out)
+{
+    if (!c) return SYMMICP_ERR_ARG;
+    if (!xyz || !nrm_out || n == 0 || n > 0x7fffffffull) return fail(c, SYMMICP_ERR_ARG, "bad cloud");
+    if (k < 3 || k > 16 || (size_t)k > n) return fail(c, SYMMICP_ERR_ARG, "k out of range (3..16, <= n)");
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (c->keep.cap == 0) {
+        // no target yet: give the keep-arena the size this cloud needs (a later set_target reuses it)
+        const size_t want = n * 96 + ((size_t)4 << 20);
+        if (hipMalloc((void **)&c->keep.base, want) == hipSuccess) { c->keep.cap = want; c->keep.off = 0; }
+        else (void)hipGetLastError();
+    }
+    const size_t keep_off0 = c->keep.off, extra0 = c->keep_extra.size();
+    const bool surf0 = c->target_surface_like;
+    float *block = nullptr, *d_nrm = nullptr, *d_curv = nullptr;
+    float4 *tq = nullptr, *tn = nullptr, *boxes = nullptr;
+    uint2 *cells = nullptr;
+    auto cleanup = [&]() {
+        (void)hipStreamSynchronize(c->stream);
+        while (c->keep_extra.size() > extra0) { hipFree(c->keep_extra.back()); c->keep_extra.pop_back(); }
+        c->keep.off = keep_off0;
+        c->target_surface_like = surf0;
+    };
+    // the cloud has no normals yet: stage xyz twice (the normal slots are ignored)
+    arena_begin(c->arena, n * (96 + 8 * row_stride + 16) + ((size_t)1 << 20));
+    int st;
+    {
+        DevBuf<float> b;
+        st = upload_planar(c, xyz, row_stride, col_stride, xyz, row_stride, col_stride, n, b, /*temp=*/false, nullptr);
+        if (st != SYMMICP_OK) { cleanup(); return st; }
+        block = b.release();
+    }
+    CloudSoA cl;
+    soa_from_block(block, n, cl);
+    TargetIndex ix{};
+    DevBuf<float> b_nrm, b_curv;
+    bool ok = keep_alloc(c, (void **)&tq, sizeof(float4) * (n + 8)) == hipSuccess && keep_alloc(c, (void **)&tn, sizeof(float4) * 2 * n) == hipSuccess &&
+              b_nrm.alloc_temp(c->arena, 3 * n) == hipSuccess && b_curv.alloc_temp(c->arena, n) == hipSuccess;
+    if (!ok) { cleanup(); return fail(c, SYMMICP_ERR_HIP, "out of device memory"); }
+    d_nrm = b_nrm.p; d_curv = b_curv.p;
+    st = build_index(c, cl, (uint32_t)n, /*want_grid=*/false, tq, tn, &boxes, &cells, &ix, nullptr, nullptr);
+    if (st != SYMMICP_OK) { cleanup(); return st; }
+    const float vp0[3] = {0.f, 0.f, 0.f};
+    launch_normals_knn(ix, k, viewpoint ? viewpoint : vp0, d_nrm, d_curv, c->stream);
+    hipError_t e = hipMemcpyAsync(nrm_out, d_nrm, sizeof(float) * 3 * n, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess && curv_out) e = hipMemcpyAsync(curv_out, d_curv, sizeof(float) * n, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess) e = hipGetLastError();
+    cleanup();
+    if (e != hipSuccess) return fail(c, SYMMICP_ERR_HIP, std::string("normals: ") + hipGetErrorString(e));
+    return SYMMICP_OK;
+}
+
 int symmicp_estimate_normals(int device, const float *xyz, size_t row_stride, size_t col_stride, size_t n, int k,
                              const float viewpoint[3], float *nrm_out, float *curv_out)
 {
@@ -1401,37 +1461,9 @@ int symmicp_estimate_normals(int device, const float *xyz, size_t row_stride, si
     symmicp_ctx *c = nullptr;
     int st = symmicp_create(&cfg, &c);
     if (st != SYMMICP_OK) return st;
-    float *block = nullptr, *d_nrm = nullptr, *d_curv = nullptr;
-    float4 *tq = nullptr, *tn = nullptr, *boxes = nullptr;
-    uint2 *cells = nullptr;
-    auto cleanup = [&]() {
-        hipFree(d_nrm); hipFree(d_curv);
-        symmicp_destroy(c);             // (block, tq, tn, boxes, cells belong to the context's keep-arena)
-    };
-    // the cloud has no normals yet: stage xyz twice (the normal slots are ignored)
-    arena_begin(c->arena, n * (96 + 8 * row_stride) + ((size_t)1 << 20));
-    {
-        DevBuf<float> b;
-        st = upload_planar(c, xyz, row_stride, col_stride, xyz, row_stride, col_stride, n, b, /*temp=*/false, nullptr);
-        if (st != SYMMICP_OK) { cleanup(); return st; }
-        block = b.release();
-    }
-    CloudSoA cl;
-    soa_from_block(block, n, cl);
-    TargetIndex ix{};
-    bool ok = keep_alloc(c, (void **)&tq, sizeof(float4) * n) == hipSuccess && keep_alloc(c, (void **)&tn, sizeof(float4) * 2 * n) == hipSuccess &&
-              hipMalloc((void **)&d_nrm, sizeof(float) * 3 * n) == hipSuccess && hipMalloc((void **)&d_curv, sizeof(float) * n) == hipSuccess;
-    if (!ok) { cleanup(); return SYMMICP_ERR_HIP; }
-    st = build_index(c, cl, (uint32_t)n, /*want_grid=*/false, tq, tn, &boxes, &cells, &ix, nullptr, nullptr);
-    if (st != SYMMICP_OK) { cleanup(); return st; }
-    const float vp0[3] = {0.f, 0.f, 0.f};
-    launch_normals_knn(ix, k, viewpoint ? viewpoint : vp0, d_nrm, d_curv, c->stream);
-    hipError_t e = hipMemcpyAsync(nrm_out, d_nrm, sizeof(float) * 3 * n, hipMemcpyDeviceToHost, c->stream);
-    if (e == hipSuccess && curv_out) e = hipMemcpyAsync(curv_out, d_curv, sizeof(float) * n, hipMemcpyDeviceToHost, c->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    if (e == hipSuccess) e = hipGetLastError();
-    cleanup();
-    return e == hipSuccess ? SYMMICP_OK : SYMMICP_ERR_HIP;
+    st = symmicp_ctx_estimate_normals(c, xyz, row_stride, col_stride, n, k, viewpoint, nrm_out, curv_out);
+    symmicp_destroy(c);
+    return st;
 }
 
 // ---- multi-GPU ---------------------------------------------------------------------------------

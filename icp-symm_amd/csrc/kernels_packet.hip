@@ -517,7 +517,8 @@ void launch_pass_tree_first(const PassArgs &a_in, const TargetIndex &ix, const W
     const uint32_t nbp = ((npk + 7u) / 8u) * 8u;
     if (ev) { hipEventRecord(ev[0], s); hipEventRecord(ev[1], s); hipEventRecord(ev[2], s); }
     static const uint32_t lds_pad = getenv("SYMMICP_PACKET_LDS_PAD") ? (uint32_t)atol(getenv("SYMMICP_PACKET_LDS_PAD")) : 0u;      // occupancy experiments
-    if (ix.dbg) hipLaunchKernelGGL((k_search_packet<PKT_ALL, false, true>), dim3(nbp), dim3(64), lds_pad, s, a, ix, wl.work, 0.0f);
+    if (!nbp) { /* empty share */ }
+    else if (ix.dbg) hipLaunchKernelGGL((k_search_packet<PKT_ALL, false, true>), dim3(nbp), dim3(64), lds_pad, s, a, ix, wl.work, 0.0f);
     else hipLaunchKernelGGL((k_search_packet<PKT_ALL, false, false>), dim3(nbp), dim3(64), lds_pad, s, a, ix, wl.work, 0.0f);
     if (ev) hipEventRecord(ev[3], s);
     launch_accumulate(a, ix.tn, acc_blocks, s);

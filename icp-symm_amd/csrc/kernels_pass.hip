@@ -988,6 +988,11 @@ __global__ __launch_bounds__(256) void k_final_reduce(const double *__restrict__
                     out_dev[kNSum - 2] = u;
                     if (out_host) out_host[kNSum - 2] = u;
                     counters_to_clear[1] = 0;
+                    // appends dropped because a shard was full (sl_push): must be 0
+                    const double dr = (double)(counters_to_clear[2] + counters_to_clear[kShards * kShardStride + 2]);
+                    out_dev[kNSum - 3] = dr;
+                    if (out_host) out_host[kNSum - 3] = dr;
+                    counters_to_clear[2] = 0; counters_to_clear[kShards * kShardStride + 2] = 0;
                 }
             }
             __syncthreads();
@@ -1064,7 +1069,13 @@ __global__ __launch_bounds__(512) void k_reduce_solve(const double *__restrict__
             }
             if (!REDUCE && t == 0) s_len = (uint32_t)s_sum[kNSum - 1];             // summed over the ranks by the all-reduce
             __syncthreads();
-            if (t == 0) { s_unc = REDUCE ? counters_to_clear[1] : (uint32_t)s_sum[kNSum - 2]; if (REDUCE) counters_to_clear[1] = 0; }
+            if (t == 0) {
+                s_unc = REDUCE ? counters_to_clear[1] : (uint32_t)s_sum[kNSum - 2];
+                if (REDUCE) {
+                    counters_to_clear[1] = 0;
+                    if (counters_to_clear[2] | counters_to_clear[kShards * kShardStride + 2]) s_len = 0xFFFFFFFFu;      // dropped appends: the host redoes the pass and reports
+                } else if (s_sum[kNSum - 3] != 0.0) s_len = 0xFFFFFFFFu;
+            }
             if (REDUCE) for (int c = t; c < 2 * kShards; c += 512) counters_to_clear[c * kShardStride] = 0;
         }
     } else {
@@ -1250,10 +1261,10 @@ void launch_pass_tree_split(const PassArgs &a_in, const TargetIndex &ix, const W
     const uint32_t nb = (a.n + kPassThreads - 1) / kPassThreads;
     const uint32_t nbp = ((nb + 7u) / 8u) * 8u;
     if (ev) hipEventRecord(ev[0], s);
-    if (stage != 2) hipLaunchKernelGGL(k_search_cells, dim3(nbp), dim3(kPassThreads), 0, s, a, ix, wl);
+    if (stage != 2 && nbp) hipLaunchKernelGGL(k_search_cells, dim3(nbp), dim3(kPassThreads), 0, s, a, ix, wl);      // (nbp == 0: a rank whose share is empty)
     if (ev) hipEventRecord(ev[1], s);
     if (ev) hipEventRecord(ev[2], s);
-    if (stage != 1) {
+    if (stage != 1 && nbp) {
         if (walk_blocks == 0 || walk_blocks > walk_blocks_full(wl)) walk_blocks = walk_blocks_full(wl);
         // first pass of an alignment: no query has a bound yet, which the wave-per-query walk needs (its frontier would
         // overflow and fall back to one lane): one thread per query whatever the list length (matters for shares or

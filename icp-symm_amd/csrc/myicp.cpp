@@ -6,7 +6,7 @@
 
 MyICP::MyICP() : max_iters(10), diff_threshold(1.f),                       // myicp.cpp:6
                  mode_(SYMMICP_MODE_QUIRKS), corr_(SYMMICP_CORR_IDENTITY), verbose_(true),
-                 have_src_normals_(false), have_tgt_normals_(false)
+                 have_src_normals_(false), have_tgt_normals_(false), ctx_(nullptr), ctx_corr_(-1)
 {
 	cloud_src = pcl::PointCloud<PointT>::Ptr(new pcl::PointCloud<PointT>);
 	cloud_tgt = pcl::PointCloud<PointT>::Ptr(new pcl::PointCloud<PointT>);
@@ -18,6 +18,22 @@ MyICP::MyICP() : max_iters(10), diff_threshold(1.f),                       // my
 
 MyICP::~MyICP()
 {
+	if (ctx_) symmicp_destroy(ctx_);
+}
+
+// The context is created on first use and kept: a second RegisterSymm / align on the same object reuses its stream, its
+// arenas and the loaded code objects.  The correspondence kind decides device layouts, so changing it means a new context.
+symmicp_ctx *MyICP::context()
+{
+	if (ctx_ && ctx_corr_ != (int)corr_) { symmicp_destroy(ctx_); ctx_ = nullptr; }
+	if (!ctx_) {
+		symmicp_config cfg;
+		symmicp_config_default(&cfg);
+		cfg.corr = corr_;
+		if (symmicp_create(&cfg, &ctx_) != SYMMICP_OK) { ctx_ = nullptr; return nullptr; }
+		ctx_corr_ = (int)corr_;
+	}
+	return ctx_;
 }
 
 static bool load_one(const std::string &path, pcl::PointCloud<PointT> &out)
@@ -89,47 +105,53 @@ void MyICP::setInputTarget(const float *xyz, const float *normals, size_t n)
 
 void MyICP::estimateNormals()
 {
-	// myicp.cpp:152-172: NormalEstimation, KdTree, setKSearch(10), viewpoint (0,0,0), then concatenateFields
-	struct Job { pcl::PointCloud<PointT> *c; pcl::PointCloud<pcl::PointNormal> *pn; bool *have; };
-	Job jobs[2] = {{cloud_src.get(), cloud_pn_src.get(), &have_src_normals_}, {cloud_tgt.get(), cloud_pn_tgt.get(), &have_tgt_normals_}};
+	// myicp.cpp:152-172: NormalEstimation, KdTree, setKSearch(10), viewpoint (0,0,0), then concatenateFields -- from the
+	// clouds as they are NOW, on every call (GetSrcCloud / GetTgtCloud hand out the clouds themselves: a caller may have
+	// edited them).  Normals the caller supplied through setInput* are kept.
+	struct Job { pcl::PointCloud<PointT> *c; pcl::PointCloud<pcl::PointNormal> *pn; bool have; };
+	Job jobs[2] = {{cloud_src.get(), cloud_pn_src.get(), have_src_normals_}, {cloud_tgt.get(), cloud_pn_tgt.get(), have_tgt_normals_}};
 	for (Job &j : jobs) {
-		if (*j.have && j.pn->points.size() == j.c->points.size()) continue;
 		const size_t n = j.c->points.size();
+		if (j.have && j.pn->points.size() == n) {
+			for (size_t i = 0; i < n; i++) { j.pn->points[i].x = j.c->points[i].x; j.pn->points[i].y = j.c->points[i].y; j.pn->points[i].z = j.c->points[i].z; }
+			continue;
+		}
 		std::vector<float> nrm(3 * n, 0.f);
 		if (n >= 10) {
-			int st = symmicp_estimate_normals(-1, &j.c->points[0].x, sizeof(PointT) / sizeof(float), 1, n, 10, nullptr, nrm.data(), nullptr);
+			symmicp_ctx *ctx = context();
+			int st = ctx ? symmicp_ctx_estimate_normals(ctx, &j.c->points[0].x, sizeof(PointT) / sizeof(float), 1, n, 10, nullptr, nrm.data(), nullptr) : SYMMICP_ERR_HIP;
 			if (st != SYMMICP_OK) error_ = "symmicp_estimate_normals failed";
 		}
 		fill_pn(*j.c, nrm.data(), *j.pn);
-		*j.have = true;
 	}
 }
 
 int MyICP::align(float out4x4[16], const float *guess4x4)
 {
 	assert(cloud_src && cloud_tgt);                                        // myicp.cpp:102
+	symmicp_ctx *ctx = context();
+	if (!ctx) { error_ = "symmicp_create failed: no usable gfx950 HIP device (there is no CPU fallback)"; result_.status = SYMMICP_ERR_HIP; return SYMMICP_ERR_HIP; }
 	estimateNormals();                                                     // myicp.cpp:105
 	symmicp_config cfg;
 	symmicp_config_default(&cfg);
 	cfg.mode = mode_; cfg.corr = corr_; cfg.max_iters = max_iters; cfg.diff_threshold = diff_threshold;
 	cfg.verbose = verbose_ ? 1 : 0;
-	symmicp_ctx *ctx = nullptr;
-	int st = symmicp_create(&cfg, &ctx);
-	if (st != SYMMICP_OK) { error_ = "symmicp_create failed: no usable gfx950 HIP device (there is no CPU fallback)"; result_.status = st; return st; }
+	int st = symmicp_set_config(ctx, &cfg);
 	const size_t fs = sizeof(pcl::PointNormal) / sizeof(float);            // pasteInMatrix, func.cpp:5-15
-	if (!cloud_pn_tgt->points.empty() && !cloud_pn_src->points.empty()) {
-		st = symmicp_set_target(ctx, &cloud_pn_tgt->points[0].x, fs, 1, &cloud_pn_tgt->points[0].normal_x, fs, 1, cloud_pn_tgt->points.size());
-		if (st == SYMMICP_OK)
-			st = symmicp_set_source(ctx, &cloud_pn_src->points[0].x, fs, 1, &cloud_pn_src->points[0].normal_x, fs, 1, cloud_pn_src->points.size());
-	} else {
-		st = SYMMICP_ERR_SIZE;
+	if (st == SYMMICP_OK) {
+		if (!cloud_pn_tgt->points.empty() && !cloud_pn_src->points.empty()) {
+			st = symmicp_set_target(ctx, &cloud_pn_tgt->points[0].x, fs, 1, &cloud_pn_tgt->points[0].normal_x, fs, 1, cloud_pn_tgt->points.size());
+			if (st == SYMMICP_OK)
+				st = symmicp_set_source(ctx, &cloud_pn_src->points[0].x, fs, 1, &cloud_pn_src->points[0].normal_x, fs, 1, cloud_pn_src->points.size());
+		} else {
+			st = SYMMICP_ERR_SIZE;
+		}
 	}
 	if (st == SYMMICP_OK) st = symmicp_align(ctx, guess4x4, &result_);
 	else result_.status = st;
 	if (st != SYMMICP_OK) error_ = symmicp_last_error(ctx);
 	if (result_.iters > 0 || st == SYMMICP_OK) std::memcpy(transform_, result_.transform, sizeof(transform_));
 	if (out4x4) std::memcpy(out4x4, transform_, sizeof(transform_));
-	symmicp_destroy(ctx);
 	return st;
 }
 

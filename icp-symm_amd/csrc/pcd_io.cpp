@@ -66,13 +66,31 @@ bool parse_header(FILE *f, Header &h)
             break;
         }
     }
-    if (!data_seen || h.fields.empty()) return false;
-    if (h.points < 0) h.points = h.width * h.height;
+    if (!data_seen || h.fields.empty() || h.fields.size() > 256) return false;
+    // the header is untrusted input: every SIZE / COUNT / TYPE has to be one this reader knows how to place and load, the
+    // record has to stay small, and POINTS has to agree with WIDTH x HEIGHT when both are given
+    if (h.width >= 0 && (h.height < 0 || h.width > (long)0x7fffffff || h.height > (long)0x7fffffff)) return false;
+    const long wh = (h.width >= 0) ? h.width * h.height : -1;
+    if (h.points < 0) h.points = wh;
+    else if (wh >= 0 && wh != h.points) return false;
+    if (h.points < 0 || h.points > (long)0x7fffffff) return false;
     for (auto &fd : h.fields) {
+        if (fd.count < 1 || fd.count > 4096) return false;
+        if (fd.size != 1 && fd.size != 2 && fd.size != 4 && fd.size != 8) return false;
+        if (fd.type != 'F' && fd.type != 'U' && fd.type != 'I') return false;
+        if (fd.type == 'F' && fd.size < 4) return false;
         fd.column = h.columns; fd.offset = h.record;
         h.columns += fd.count; h.record += fd.count * fd.size;
+        if (h.record > (1 << 20) || h.columns > (1 << 16)) return false;
     }
-    return h.points >= 0;
+    return h.record > 0;
+}
+
+// a field this reader can turn into a float (the x / y / z / normal_* fields have to be)
+bool loadable(const Field &fd)
+{
+    if (fd.type == 'F') return fd.size == 4 || fd.size == 8;
+    return fd.size == 1 || fd.size == 2 || fd.size == 4;
 }
 
 float load_scalar(const unsigned char *p, const Field &fd)
@@ -100,6 +118,11 @@ extern "C" long symmicp_pcd_read(const char *path, float *xyz, float *nrm, size_
     const int inx = h.find("normal_x"), iny = h.find("normal_y"), inz = h.find("normal_z");
     if (ix < 0 || iy < 0 || iz < 0) { std::fclose(f); return -SYMMICP_ERR_IO; }
     const bool hn = inx >= 0 && iny >= 0 && inz >= 0;
+    {
+        bool ok = loadable(h.fields[ix]) && loadable(h.fields[iy]) && loadable(h.fields[iz]);
+        if (hn) ok = ok && loadable(h.fields[inx]) && loadable(h.fields[iny]) && loadable(h.fields[inz]);
+        if (!ok) { std::fclose(f); return -SYMMICP_ERR_IO; }
+    }
     if (has_normals) *has_normals = hn ? 1 : 0;
     if (!xyz) { std::fclose(f); return h.points; }
     if ((size_t)h.points > cap) { std::fclose(f); return -SYMMICP_ERR_SIZE; }

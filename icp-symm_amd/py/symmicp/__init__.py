@@ -73,7 +73,7 @@ EXPORTS = [
     "symmicp_get_transform", "symmicp_get_pivot", "symmicp_get_correspondences", "symmicp_get_source",
     "symmicp_local_source_count", "symmicp_local_source_offset", "symmicp_solve", "symmicp_comm_get_unique_id",
     "symmicp_comm_init_rank", "symmicp_set_sums", "symmicp_comm_init_shm", "symmicp_shard_range", "symmicp_get_stats", "symmicp_reset_stats", "symmicp_enable_timing",
-    "symmicp_pcd_read", "symmicp_pcd_write", "symmicp_estimate_normals",
+    "symmicp_pcd_read", "symmicp_pcd_write", "symmicp_estimate_normals", "symmicp_ctx_estimate_normals",
 ]
 
 _lib = None

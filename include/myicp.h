@@ -40,6 +40,8 @@ public:
 	const float *getFinalTransformation() const { return transform_; }       // row-major 4x4
 	// the source cloud moved by the final transform (the reference never writes its result back: myicp.cpp:109-111,146-149)
 	pcl::PointCloud<PointT>::Ptr GetAlignedSrcCloud() const;
+	MyICP(const MyICP &) = delete;
+	MyICP &operator=(const MyICP &) = delete;
 	void setMaximumIterations(int n) { max_iters = n; }
 	void setDiffThreshold(float d) { diff_threshold = d; }
 	void setMode(symmicp_mode m) { mode_ = m; }                    // default SYMMICP_MODE_QUIRKS (= the reference)
@@ -57,9 +59,13 @@ private:
 
 	void estimateNormals();
 
+	symmicp_ctx *context();              // one libsymmicp context for the life of the object (stream, arenas, code objects)
+
 	symmicp_mode mode_;
 	symmicp_corr corr_;
-	bool verbose_, have_src_normals_, have_tgt_normals_;
+	bool verbose_, have_src_normals_, have_tgt_normals_;   // have_*: normals supplied by the caller through setInput*
+	symmicp_ctx *ctx_;
+	int ctx_corr_;
 	float transform_[16];
 	symmicp_result result_;
 	std::string error_;

@@ -171,6 +171,10 @@ int symmicp_solve(int mode, const symmicp_sums *sums, const float pivot[3],
  * viewpoint may be NULL (origin); 3 <= k <= 16. */
 int symmicp_estimate_normals(int device, const float *xyz, size_t row_stride, size_t col_stride, size_t n, int k,
                              const float viewpoint[3], float *nrm_out, float *curv_out);
+/* the same on a context the caller already owns (stream, arenas and code objects are reused; the context's own clouds are
+ * left alone): what MyICP::estimateNormals calls for both clouds before every alignment (myicp.cpp:105) */
+int symmicp_ctx_estimate_normals(symmicp_ctx *ctx, const float *xyz, size_t row_stride, size_t col_stride, size_t n, int k,
+                                 const float viewpoint[3], float *nrm_out, float *curv_out);
 
 /* ---- multi-GPU (new: the reference is single-threaded) ----- */
 /* rank 0 creates an id, the application ships it to the other ranks (any channel),

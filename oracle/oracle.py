@@ -141,6 +141,17 @@ def solve_quirks_gram(S):
     return st, pbar, qbar, a, t, rc.value
 
 
+def compose_quirks(pbar, qbar, a, t):
+    """func.cpp:91-99: the five post-multiplied factors -> row-major 4x4"""
+    L = lib()
+    fp = C.POINTER(C.c_float)
+    v = [np.ascontiguousarray(x, np.float32) for x in (pbar, qbar, a, t)]
+    X = np.zeros(16, np.float32)
+    L.orc_compose_quirks.restype = None
+    L.orc_compose_quirks(*[x.ctypes.data_as(fp) for x in v], X.ctypes.data_as(fp))
+    return X.reshape(4, 4)
+
+
 def solve_quirks_literal(p, np_, q, nq):
     L = lib()
     p, pp = _xyz(p); np_, npp = _xyz(np_); q, qp = _xyz(q); nq, nqp = _xyz(nq)

@@ -103,6 +103,32 @@ def test_pcd_io_roundtrip(sym, oracle, tmp_path):
         sym.pcd_read(str(tmp_path / "missing.pcd"))
 
 
+@pytest.mark.parametrize("bad", ["negative_size", "zero_count", "size_3", "type_x", "points_mismatch", "huge_record", "f2_xyz", "no_data"])
+def test_pcd_reader_rejects_malformed_headers(sym, tmp_path, bad):
+    """The PCD header is untrusted input (the reference hands it to pcl::PCDReader and ignores the status, myicp.cpp:22-30):
+    sizes, counts and types this reader cannot place or load are refused with an I/O error instead of being trusted."""
+    hdr = dict(FIELDS="x y z", SIZE="4 4 4", TYPE="F F F", COUNT="1 1 1", WIDTH="2", HEIGHT="1", POINTS="2", DATA="ascii")
+    if bad == "negative_size": hdr["SIZE"] = "4 -4 4"
+    if bad == "zero_count": hdr["COUNT"] = "1 0 1"
+    if bad == "size_3": hdr["SIZE"] = "4 3 4"
+    if bad == "type_x": hdr["TYPE"] = "F X F"
+    if bad == "points_mismatch": hdr["POINTS"] = "5"
+    if bad == "huge_record": hdr["COUNT"] = "1 1 4000"; hdr["SIZE"] = "4 4 8"; hdr["FIELDS"] = "x y z"; hdr["COUNT"] = "4000 4000 4000"
+    if bad == "f2_xyz": hdr["SIZE"] = "2 2 2"
+    if bad == "no_data": del hdr["DATA"]
+    p = tmp_path / "bad.pcd"
+    with open(p, "w") as f:
+        f.write("# .PCD v0.7\nVERSION 0.7\n")
+        for k in ("FIELDS", "SIZE", "TYPE", "COUNT", "WIDTH", "HEIGHT"):
+            f.write("%s %s\n" % (k, hdr[k]))
+        f.write("VIEWPOINT 0 0 0 1 0 0 0\nPOINTS %s\n" % hdr["POINTS"])
+        if "DATA" in hdr:
+            f.write("DATA ascii\n")
+        f.write("0 0 0\n1 1 1\n")
+    with pytest.raises(sym.SymmIcpError):
+        sym.pcd_read(str(p))
+
+
 def test_reference_main_cpp_compiles_unchanged_against_the_dropin(sym, tmp_path):
     """The reference's own driver (ICP/main.cpp), byte for byte, builds against include/myicp.h +
     include/stdafx.h + the pcl:: stand-in and links with libsymmicp.  Only where /root/reference is

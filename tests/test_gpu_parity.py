@@ -449,13 +449,14 @@ def test_8m_surface_properties(sym, oracle):
 
 
 def test_cpp_driver_prints_the_reference_lines(cat, tmp_path):
-    """examples/main.cpp (the reference's ICP/main.cpp call sequence) through the C++ MyICP class:
-    stdout carries the reference's lines (myicp.cpp:125-126,146-149) and the oracle's numbers."""
+    """examples/icp_align.cpp (the repo's driver for the C++ MyICP class) run the way the reference's main.cpp runs
+    (cat.pcd -> cat_out.pcd, defaults): stdout carries the reference's lines (myicp.cpp:125-126,146-149) and the oracle's
+    numbers; --out writes the moved source."""
     import os
     import shutil
     import subprocess
     from conftest import ROOT, GOLDEN
-    exe = os.path.join(ROOT, "icp-symm_amd", "bin", "icp_main")
+    exe = os.path.join(ROOT, "icp-symm_amd", "bin", "icp_align")
     assert os.path.exists(exe), "run __graft_entry__.build()"
     shutil.copy(os.path.join(GOLDEN, "cat.pcd"), tmp_path / "cat.pcd")
     shutil.copy(os.path.join(GOLDEN, "cat_out.pcd"), tmp_path / "cat_out.pcd")
@@ -469,6 +470,41 @@ def test_cpp_driver_prints_the_reference_lines(cat, tmp_path):
     # normals come from the GPU k-NN PCA here, from the oracle's in the golden file: same to fp noise
     assert np.abs(T - cat["golden"]["quirks_identity_T"]).max() < 5e-4
     assert "  rotation:" in out and "  translation:" in out
+    # paper-correct run with nearest neighbours, explicit file names and an output cloud
+    r = subprocess.run([exe, "--mode", "paper", "--corr", "tree", "--iters", "30", "--quiet", "--out", "moved.pcd", "cat.pcd", "cat_out.pcd"],
+                       cwd=tmp_path, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    import symmicp
+    moved, _ = symmicp.pcd_read(str(tmp_path / "moved.pcd"))
+    assert np.abs(moved - cat["tgt"]).max() < 1e-2          # cat_out = Rz(45) cat + (2.5, 0, 0), same row order
+    assert subprocess.run([exe, "--mode", "nonsense"], cwd=tmp_path, capture_output=True).returncode == 64
+
+
+def test_cpp_myicp_surface(cat, oracle, tmp_path):
+    """The C++ surface BASELINE.json's north_star names -- setInputSource / setInputTarget / align(out, guess) /
+    getFinalTransformation / GetAlignedSrcCloud on the C++ MyICP (include/myicp.h, replacing ICP/myicp.h:14-19) -- driven
+    by tests/cpp/myicp_surface.cpp with packed arrays; the 4x4s it returns are compared with the oracle here."""
+    import subprocess
+    from conftest import ROOT
+    exe = os.path.join(ROOT, "icp-symm_amd", "bin", "test_myicp_surface")
+    assert os.path.exists(exe), "run __graft_entry__.build()"
+    G = np.eye(4, dtype=np.float32)
+    c, s = np.cos(np.deg2rad(40.0)), np.sin(np.deg2rad(40.0))
+    G[:2, :2] = [[c, -s], [s, c]]
+    G[0, 3] = 2.0
+    for name, arr in (("src", cat["src"]), ("src_n", cat["src_n"]), ("tgt", cat["tgt"]), ("tgt_n", cat["tgt_n"]), ("guess", G)):
+        np.ascontiguousarray(arr, np.float32).tofile(tmp_path / (name + ".f32"))
+    r = subprocess.run([exe, str(tmp_path)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    Tp = np.fromfile(tmp_path / "out_paper_tree.f32", np.float32).reshape(4, 4)
+    Tq = np.fromfile(tmp_path / "out_quirks_identity.f32", np.float32).reshape(4, 4)
+    moved = np.fromfile(tmp_path / "aligned_paper_tree.f32", np.float32).reshape(-1, 3)
+    ro = oracle.align(cat["src"], cat["src_n"], cat["tgt"], cat["tgt_n"], mode=oracle.MODE_PAPER, corr=oracle.CORR_BRUTE, max_iters=30, guess=G)
+    assert np.abs(Tp - ro["transform"]).max() < 1e-4
+    truth = np.array([[np.cos(np.pi / 4), -np.sin(np.pi / 4), 0, 2.5], [np.sin(np.pi / 4), np.cos(np.pi / 4), 0, 0], [0, 0, 1, 0], [0, 0, 0, 1]])
+    assert np.abs(Tp - truth).max() < 1e-4
+    assert np.abs(moved - cat["tgt"]).max() < 1e-2
+    assert np.abs(Tq - cat["golden"]["quirks_identity_T"]).max() < 1.5e-4      # same normals as the golden run (supplied, not estimated)
 
 
 def test_rccl_path_single_rank_communicator(sym, cat, monkeypatch):
