@@ -723,15 +723,20 @@ int symmicp_set_source(symmicp_ctx *c, const float *xyz, size_t xr, size_t xc, c
     const double t0 = now_s();
     forget_source(c);
     c->begun = false;
-    arena_begin(c->arena, n * (48 + 4 * (xr + nr)) + ((size_t)1 << 20));
-    DevBuf<float> full;
-    int st = upload_planar(c, xyz, xr, xc, nrm, nr, nc, n, full, /*temp=*/true, nullptr);
-    if (st != SYMMICP_OK) return st;
-    CloudSoA fs;
-    soa_from_block(full.p, n, fs);
-    // contiguous share of the (sorted) source for this rank
+    // This rank's share is a contiguous block of the CALLER's rows, and only those rows are uploaded and sorted: set_source costs
+    // 1/nranks of the single-GPU call on every rank (round 1 uploaded and sorted the whole cloud on every rank and kept a
+    // slice of the global Morton order).  Any partition of the source is exact -- queries are independent given the
+    // transform -- and the share's own Morton sort below gives the waves their locality.
     size_t b0 = 0, bc = 0;
     symmicp_shard_range(n, c->nranks, c->rank, &b0, &bc);
+    const size_t nu = bc > 0 ? bc : 1;                       // rows uploaded (an empty share still stages one row)
+    const size_t r0 = bc > 0 ? b0 : 0;
+    arena_begin(c->arena, nu * (48 + 4 * (xr + nr)) + ((size_t)1 << 20));
+    DevBuf<float> full;
+    int st = upload_planar(c, xyz + r0 * xr, xr, xc, nrm + r0 * nr, nr, nc, nu, full, /*temp=*/true, nullptr);
+    if (st != SYMMICP_OK) return st;
+    CloudSoA fs;
+    soa_from_block(full.p, nu, fs);
     const uint32_t nl = bc > 0 ? (uint32_t)bc : 1;
     const bool sorted = c->cfg.corr != SYMMICP_CORR_IDENTITY && c->cfg.sort_source;
     const bool tree = c->cfg.corr == SYMMICP_CORR_TREE, brute = c->cfg.corr == SYMMICP_CORR_BRUTE;
@@ -766,18 +771,15 @@ int symmicp_set_source(symmicp_ctx *c, const float *xyz, size_t xr, size_t xc, c
     if (sorted) {
         DevBuf<uint32_t> order;
         float origin[3], h0;
-        st = morton_order(c, fs, (uint32_t)n, order, nullptr, origin, &h0);
+        st = morton_order(c, fs, (uint32_t)nu, order, nullptr, origin, &h0);
         if (st != SYMMICP_OK) { forget_source(c); return st; }
         c->src_order = reinterpret_cast<uint32_t *>(c->src_all + o_order);
         if (c->n_loc) {
-            HIP_TRY(c, hipMemcpyAsync(c->src_order, order.p + b0, sizeof(uint32_t) * c->n_loc, hipMemcpyDeviceToDevice, c->stream));
-            launch_gather_soa(fs, c->src_order, c->n_loc, c->src0, c->stream);
+            launch_gather_soa(fs, order.p, c->n_loc, c->src0, c->stream);               // share position -> row of the uploaded block
+            launch_offset_u32(order.p, (uint32_t)b0, c->n_loc, c->src_order, c->stream); // ... -> row of the caller's cloud
         }
     } else if (c->n_loc) {
-        const float *from[6] = {fs.x, fs.y, fs.z, fs.nx, fs.ny, fs.nz};
-        float *to[6] = {c->src0.x, c->src0.y, c->src0.z, c->src0.nx, c->src0.ny, c->src0.nz};
-        for (int k = 0; k < 6; k++)
-            HIP_TRY(c, hipMemcpyAsync(to[k], from[k] + b0, sizeof(float) * c->n_loc, hipMemcpyDeviceToDevice, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(c->src0_block, full.p, sizeof(float) * 6 * c->n_loc, hipMemcpyDeviceToDevice, c->stream));
     }
     if (tree) {
         c->cert = reinterpret_cast<float *>(c->src_all + o_cert);
@@ -815,6 +817,8 @@ static void flush_events(symmicp_ctx *c)
         }
         c->st.last_pass_ms = pass_ms;
         c->st.sum_pass_ms += pass_ms;
+        if (c->st.passes_timed < 8) c->st.pass_ms_head[c->st.passes_timed] = pass_ms;
+        c->st.passes_timed++;
     }
     c->ev_used = 0;
 }
@@ -1578,7 +1582,8 @@ int symmicp_reset_stats(symmicp_ctx *c)
     flush_events(c);
     c->st.last_pass_ms = c->st.sum_pass_ms = 0.0;
     c->st.passes = 0;
-    for (int k = 0; k < 8; k++) { c->st.kernel_ms[k] = 0.0; c->st.kernel_launches[k] = 0; }
+    c->st.passes_timed = 0;
+    for (int k = 0; k < 8; k++) { c->st.kernel_ms[k] = 0.0; c->st.kernel_launches[k] = 0; c->st.pass_ms_head[k] = 0.0; }
     return SYMMICP_OK;
 }
 

@@ -500,6 +500,17 @@ void launch_iota_f4(const float *x, const float *y, const float *z, const float 
     hipLaunchKernelGGL(k_gather_f4, dim3(nblk(n, 256)), dim3(256), 0, s, x, y, z, nx, ny, nz, (const uint32_t *)nullptr, n, tq, tn);
 }
 
+__global__ __launch_bounds__(256) void k_offset_u32(const uint32_t *__restrict__ in, uint32_t off, uint32_t n, uint32_t *__restrict__ out)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = in[i] + off;
+}
+
+void launch_offset_u32(const uint32_t *in, uint32_t off, uint32_t n, uint32_t *out, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_offset_u32, dim3(nblk(n, 256)), dim3(256), 0, s, in, off, n, out);
+}
+
 void launch_gather_soa(const CloudSoA &src, const uint32_t *order, uint32_t n, CloudSoA dst, hipStream_t s)
 {
     hipLaunchKernelGGL(k_gather_soa, dim3(nblk(n, 256)), dim3(256), 0, s, src, order, n, dst);

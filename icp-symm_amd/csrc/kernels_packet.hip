@@ -270,41 +270,39 @@ __device__ __noinline__ void pkt_dfs(const float4 *__restrict__ onodes, const fl
     }
 }
 
-// Where the packets come from:
-//   PKT_ALL   the queries [0, n) in order, 64 per packet (first pass of an alignment: no previous pairs)
-//   PKT_LIST  consecutive entries of `list`, 64 per packet (queries another kernel could not settle); the current distance
-//             to the previous pair's point (d2_out[i], with pos_out[i] >= 0) bounds each lane
-enum { PKT_ALL = 0, PKT_LIST = 1 };
+// The packets are the queries [0, n) in order, 64 per packet: the first pass of an alignment (no previous pairs, every query is
+// searched from scratch).  Later passes have bounds from their previous pairs and mostly certificates; packets were measured
+// there too (previous pair as the bound, certificate test per lane) and lose to the cell scans of k_search_cells: 0.55 ms
+// against 0.35 ms for pass 2 of the 1M-point surface pair, 0.56 against 0.17 for pass 3 -- with tight bounds a packet is ten
+// nearly empty levels of round trips.
 constexpr int kFrontCap = 512;            // frontier nodes per level (two buffers of uint32 in LDS = the DFS stack's 4 KB)
 static_assert(2 * kFrontCap * sizeof(uint32_t) == kPktStack * 2 * sizeof(float4), "frontier buffers alias the DFS stack");
 
 #ifndef PKT_WAVES
 #define PKT_WAVES 4
 #endif
-template <int SRC, bool CERT, bool DBG>
-__global__ __launch_bounds__(64, PKT_WAVES) void k_search_packet(PassArgs a, TargetIndex ix, ShardList list, float pad)
+template <bool DBG>
+__global__ __launch_bounds__(64, PKT_WAVES) void k_search_packet(PassArgs a, TargetIndex ix)
 {
     __shared__ float4 s_buf[kPktStack][2];         // BFS: two frontier buffers; DFS fallback: the stack
     __shared__ float s_sb[4][8];                   // bounding boxes of the four 16-query sub-groups
     __shared__ uint32_t s_off[kMortonBits + 2];
-    __shared__ uint32_t pre[kShards + 1];
     uint32_t (*fr)[kFrontCap] = reinterpret_cast<uint32_t (*)[kFrontCap]>(&s_buf[0][0]);
     const int lane = threadIdx.x;
     const float inf = __int_as_float(0x7f800000);
     if (lane < kMortonBits + 2) s_off[lane] = ix.olevel_off[lane];
-    uint32_t npk;
-    if (SRC == PKT_LIST) { sl_prefix(list, pre); npk = (pre[kShards] + 63u) >> 6; }
-    else { __syncthreads(); npk = (a.n + 63u) >> 6; }
+    __syncthreads();
+    const uint32_t npk = (a.n + 63u) >> 6;
+    constexpr bool CERT = false;              // the first pass leaves no certificates (the cloud is about to move by its whole misalignment)
+    const float pad = 0.0f;
     const float4 *__restrict__ tq = ix.tq;
     const float4 *__restrict__ onodes = ix.onodes;
     PktCounters cn = {0, 0, 0, 0, 0, 0, 0};
-    for (uint32_t pk = (SRC == PKT_LIST) ? blockIdx.x : xcd_remap(blockIdx.x, gridDim.x); pk < npk; pk += gridDim.x) {
+    for (uint32_t pk = xcd_remap(blockIdx.x, gridDim.x); pk < npk; pk += gridDim.x) {
         unsigned long long t_start = 0;
         if (DBG) t_start = __builtin_amdgcn_s_memrealtime();
-        uint32_t i = pk * 64u + (uint32_t)lane;
-        bool active;
-        if (SRC == PKT_LIST) active = sl_locate(list, pre, i, i);
-        else active = i < a.n;
+        const uint32_t i = pk * 64u + (uint32_t)lane;
+        const bool active = i < a.n;
         float px = 0.f, py = 0.f, pz = 0.f;
         PktBest b;
         b.d2 = inf; b.second = 0x7f800000u; b.pos = -1;
@@ -312,13 +310,7 @@ __global__ __launch_bounds__(64, PKT_WAVES) void k_search_packet(PassArgs a, Tar
         if (active) {
             const float x = a.in.x[i], y = a.in.y[i], z = a.in.z[i];
             px = xf_row(a.X.m + 0, x, y, z, 1.0f); py = xf_row(a.X.m + 4, x, y, z, 1.0f); pz = xf_row(a.X.m + 8, x, y, z, 1.0f);
-            thr = inf;
-            if (SRC == PKT_LIST) {
-                // the provisional pair only bounds the search: its point is met again in the scan and wins (or ties) there
-                const float d0 = a.d2_out[i];
-                if (a.pos_out[i] >= 0 && d0 < inf) thr = pkt_threshold(d0, pad);
-            }
-            if (!((px == px) & (py == py) & (pz == pz))) thr = -1.0f;      // NaN query: no pair
+            thr = ((px == px) & (py == py) & (pz == pz)) ? inf : -1.0f;      // NaN query: no pair
         }
         const unsigned long long wants0 = __ballot(thr >= 0.0f);
         uint32_t steps_pk = 0;
@@ -492,7 +484,7 @@ __global__ __launch_bounds__(64, PKT_WAVES) void k_search_packet(PassArgs a, Tar
             atomicAdd(ix.dbg + 7, dt);
             if (ix.dbg_trace && (size_t)pk < ((size_t)1 << 21)) {
                 ix.dbg_trace[2 * (size_t)pk] = t_start;
-                ix.dbg_trace[2 * (size_t)pk + 1] = (dt << 32) | ((unsigned long long)(steps_pk & 0xFFFFFFu) << 8) | ((unsigned long long)SRC << 1) | (unsigned long long)(ovf_pk ? 1u : 0u);
+                ix.dbg_trace[2 * (size_t)pk + 1] = (dt << 32) | ((unsigned long long)(steps_pk & 0xFFFFFFu) << 8) | (unsigned long long)(ovf_pk ? 1u : 0u);
             }
         }
     }
@@ -509,7 +501,7 @@ __global__ __launch_bounds__(64, PKT_WAVES) void k_search_packet(PassArgs a, Tar
 // first pass of an alignment: no previous pairs, every query is searched -- packets over the whole (sorted) share
 void launch_accumulate(const PassArgs &a, const float4 *tn, int blocks, hipStream_t s);
 
-void launch_pass_tree_first(const PassArgs &a_in, const TargetIndex &ix, const WorkLists &wl, int acc_blocks, hipStream_t s, hipEvent_t *ev)
+void launch_pass_tree_first(const PassArgs &a_in, const TargetIndex &ix, const WorkLists &, int acc_blocks, hipStream_t s, hipEvent_t *ev)
 {
     PassArgs a = a_in;
     a.refresh_records = 1;
@@ -518,8 +510,8 @@ void launch_pass_tree_first(const PassArgs &a_in, const TargetIndex &ix, const W
     if (ev) { hipEventRecord(ev[0], s); hipEventRecord(ev[1], s); hipEventRecord(ev[2], s); }
     static const uint32_t lds_pad = getenv("SYMMICP_PACKET_LDS_PAD") ? (uint32_t)atol(getenv("SYMMICP_PACKET_LDS_PAD")) : 0u;      // occupancy experiments
     if (!nbp) { /* empty share */ }
-    else if (ix.dbg) hipLaunchKernelGGL((k_search_packet<PKT_ALL, false, true>), dim3(nbp), dim3(64), lds_pad, s, a, ix, wl.work, 0.0f);
-    else hipLaunchKernelGGL((k_search_packet<PKT_ALL, false, false>), dim3(nbp), dim3(64), lds_pad, s, a, ix, wl.work, 0.0f);
+    else if (ix.dbg) hipLaunchKernelGGL((k_search_packet<true>), dim3(nbp), dim3(64), lds_pad, s, a, ix);
+    else hipLaunchKernelGGL((k_search_packet<false>), dim3(nbp), dim3(64), lds_pad, s, a, ix);
     if (ev) hipEventRecord(ev[3], s);
     launch_accumulate(a, ix.tn, acc_blocks, s);
     if (ev) hipEventRecord(ev[4], s);

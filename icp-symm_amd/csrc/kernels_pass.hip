@@ -458,9 +458,9 @@ __device__ __forceinline__ void cells_tile(const PassArgs &a, const TargetIndex 
     }
     if (count_uncertified) {
         // how many pairs had to be searched this pass: tells the host when the alignment has converged far enough for the fused
-        // pass (engine.cpp, batch_eligible); word 1 of the work list's counter block is free (counters sit 16 words apart)
+        // pass (engine.cpp, batch_eligible); word 1 behind each shard counter of the work list is free (counters sit 16 words apart)
         const unsigned long long mu = __ballot(uncert);
-        if (lane == 0 && mu) atomicAdd(wl.work.counts + 1, (uint32_t)__popcll(mu));
+        if (lane == 0 && mu) atomicAdd(wl.work.counts + shard * kShardStride + 1, (uint32_t)__popcll(mu));      // (one word per shard: a single word saturates near 88 atomics per microsecond)
     }
     s_px[tid] = px; s_py[tid] = py; s_pz[tid] = pz;
     s_pos[tid] = b.pos;
@@ -683,7 +683,7 @@ __global__ __launch_bounds__(kPassThreads, FUSED_WAVES) void k_pass_fused(PassAr
     }
     __syncthreads();
     const uint32_t cnt = min(s_cnt, (uint32_t)kFusedList);
-    if (threadIdx.x == 0 && s_cnt) atomicAdd(wl.work.counts + 1, s_cnt);          // pairs that had to be searched (see cells_tile)
+    if (threadIdx.x == 0 && s_cnt) atomicAdd(wl.work.counts + (blockIdx.x & (kShards - 1)) * kShardStride + 1, s_cnt);          // pairs that had to be searched (see cells_tile)
     // ---- scan
     for (uint32_t base = 0; base < cnt; base += kPassThreads) {
         const uint32_t e = base + threadIdx.x;
@@ -938,6 +938,24 @@ __global__ __launch_bounds__(kPassThreads) void k_accumulate(PassArgs a, const f
     acc_block_reduce_store(acc, a.partials, gridDim.x);
 }
 
+// The append lists' bookkeeping words, read by the 64 lanes of one wave at once (three independent loads per lane):
+//   word 0 of shard t   entries in shard t of the work list          -> len      (summed over the shards)
+//   word 1 of shard t   pairs searched this pass, counted per shard  -> searched
+//   word 2 of a list    appends dropped because a shard was full     -> dropped  (work + retry list; must be 0)
+// Results are valid in every lane.
+__device__ __forceinline__ void read_list_words(const uint32_t *cnt, int t, uint32_t &len, uint32_t &searched, uint32_t &dropped)
+{
+    uint32_t v = cnt[t * kShardStride], u = cnt[t * kShardStride + 1];
+    uint32_t d = (t < 2) ? cnt[t * kShards * kShardStride + 2] : 0u;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        v += (uint32_t)__shfl_xor((int)v, off, 64);
+        u += (uint32_t)__shfl_xor((int)u, off, 64);
+        d += (uint32_t)__shfl_xor((int)d, off, 64);
+    }
+    len = v; searched = u; dropped = d;
+}
+
 // ---------------------------------------------------------------------------
 // final reduce: partials[40][nblocks] -> 40 doubles.  One 256-thread block per sum: coalesced
 // independent loads, then a fixed pairwise tree in LDS (deterministic).  Writes the device record
@@ -976,26 +994,18 @@ __global__ __launch_bounds__(256) void k_final_reduce(const double *__restrict__
         if (counters_to_clear) {
             __shared__ uint32_t s_len;
             if (t < 64) {
-                uint32_t v = counters_to_clear[t * kShardStride];
-#pragma unroll
-                for (int off = 32; off > 0; off >>= 1) v += (uint32_t)__shfl_xor((int)v, off, 64);
+                uint32_t len, searched, dropped;
+                read_list_words(counters_to_clear, t, len, searched, dropped);
                 if (t == 0) {
-                    s_len = v;
-                    out_dev[kNSum - 1] = (double)v;
-                    if (out_host) out_host[kNSum - 1] = (double)v;
-                    // pairs searched this pass (cells_tile): travels in the slot before, cleared for the next pass
-                    const double u = (double)counters_to_clear[1];
-                    out_dev[kNSum - 2] = u;
-                    if (out_host) out_host[kNSum - 2] = u;
-                    counters_to_clear[1] = 0;
-                    // appends dropped because a shard was full (sl_push): must be 0
-                    const double dr = (double)(counters_to_clear[2] + counters_to_clear[kShards * kShardStride + 2]);
-                    out_dev[kNSum - 3] = dr;
-                    if (out_host) out_host[kNSum - 3] = dr;
-                    counters_to_clear[2] = 0; counters_to_clear[kShards * kShardStride + 2] = 0;
+                    s_len = len;
+                    // the record's spare slots: list length, pairs searched this pass (cells_tile), dropped appends (sl_push: must be 0)
+                    out_dev[kNSum - 1] = (double)len; out_dev[kNSum - 2] = (double)searched; out_dev[kNSum - 3] = (double)dropped;
+                    if (out_host) { out_host[kNSum - 1] = (double)len; out_host[kNSum - 2] = (double)searched; out_host[kNSum - 3] = (double)dropped; }
                 }
             }
             __syncthreads();
+            if (t < 2) counters_to_clear[t * kShards * kShardStride + 2] = 0;
+            if (t < kShards) counters_to_clear[t * kShardStride + 1] = 0;
             if (!(keep_nonempty && s_len > 0u))
                 for (int c = t; c < 2 * kShards; c += 256) counters_to_clear[c * kShardStride] = 0;      // work list and retry list
         }
@@ -1061,22 +1071,22 @@ __global__ __launch_bounds__(512) void k_reduce_solve(const double *__restrict__
         } else if (t < kNSum) s_sum[t] = out_dev[t];
         __syncthreads();
         if (counters_to_clear) {
-            if (REDUCE && t < 64) {
-                uint32_t v = counters_to_clear[t * kShardStride];                  // the work list's shards
-#pragma unroll
-                for (int off = 32; off > 0; off >>= 1) v += (uint32_t)__shfl_xor((int)v, off, 64);
-                if (t == 0) s_len = v;
+            if (REDUCE) {
+                if (t < 64) {
+                    uint32_t len, searched, dropped;
+                    read_list_words(counters_to_clear, t, len, searched, dropped);
+                    if (t == 0) { s_len = dropped ? 0xFFFFFFFFu : len; s_unc = searched; }      // dropped appends: the host redoes the pass and reports
+                }
+            } else if (t == 0) {
+                // summed over the ranks by the all-reduce (k_final_reduce put them in the record)
+                s_len = (s_sum[kNSum - 3] != 0.0) ? 0xFFFFFFFFu : (uint32_t)s_sum[kNSum - 1];
+                s_unc = (uint32_t)s_sum[kNSum - 2];
             }
-            if (!REDUCE && t == 0) s_len = (uint32_t)s_sum[kNSum - 1];             // summed over the ranks by the all-reduce
             __syncthreads();
-            if (t == 0) {
-                s_unc = REDUCE ? counters_to_clear[1] : (uint32_t)s_sum[kNSum - 2];
-                if (REDUCE) {
-                    counters_to_clear[1] = 0;
-                    if (counters_to_clear[2] | counters_to_clear[kShards * kShardStride + 2]) s_len = 0xFFFFFFFFu;      // dropped appends: the host redoes the pass and reports
-                } else if (s_sum[kNSum - 3] != 0.0) s_len = 0xFFFFFFFFu;
+            if (REDUCE) {
+                if (t < kShards) counters_to_clear[t * kShardStride + 1] = 0;
+                for (int c = t; c < 2 * kShards; c += 512) counters_to_clear[c * kShardStride] = 0;
             }
-            if (REDUCE) for (int c = t; c < 2 * kShards; c += 512) counters_to_clear[c * kShardStride] = 0;
         }
     } else {
         if (t < kNSum) s_sum[t] = out_dev[t];

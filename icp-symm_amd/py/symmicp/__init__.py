@@ -60,7 +60,7 @@ class Stats(C.Structure):
     _fields_ = [("last_pass_ms", C.c_double), ("sum_pass_ms", C.c_double), ("passes", C.c_int64),
                 ("build_ms", C.c_double), ("upload_ms", C.c_double), ("grid_level", C.c_int32),
                 ("tree_levels", C.c_int32), ("pass_blocks", C.c_int64), ("bytes_algorithmic_per_pass", C.c_int64),
-                ("kernel_ms", C.c_double * 8), ("kernel_launches", C.c_int64 * 8)]
+                ("kernel_ms", C.c_double * 8), ("kernel_launches", C.c_int64 * 8), ("pass_ms_head", C.c_double * 8), ("passes_timed", C.c_int64)]
 
 
 KERNEL_SLOTS = ["k_search_cells", "(gap)", "k_search_walk", "k_accumulate", "k_final_reduce", "single_pass_kernel", "whole_pass"]
@@ -387,6 +387,7 @@ class Engine:
         d = {k: getattr(s, k) for k, _ in Stats._fields_}
         d["kernel_ms"] = list(s.kernel_ms)
         d["kernel_launches"] = list(s.kernel_launches)
+        d["pass_ms_head"] = list(s.pass_ms_head)
         return d
 
 

@@ -135,8 +135,8 @@ int symmicp_version(void);
  *   pcl::PointNormal      xyz: base=&pt[0].x, 12,1 ; normals: base=&pt[0].normal_x, 12,1
  *   Eigen::MatrixXf Nx3   row_stride=1, col_stride=N   (column-major)
  * Data is copied to the device; the caller keeps ownership.  With a
- * communicator attached every rank passes the FULL cloud and keeps only its
- * contiguous share of the (Morton-sorted) source; the target is replicated.
+ * communicator attached every rank passes the FULL cloud (same pointer arithmetic on every rank) and uploads only its own
+ * share: rows [begin, begin + count) of symmicp_shard_range, Morton-sorted on the device; the target is replicated.
  * set_target also builds the search index when corr != IDENTITY. */
 int symmicp_set_source(symmicp_ctx *ctx, const float *xyz, size_t xyz_row_stride, size_t xyz_col_stride,
                        const float *nrm, size_t nrm_row_stride, size_t nrm_col_stride, size_t n);
@@ -181,7 +181,7 @@ int symmicp_ctx_estimate_normals(symmicp_ctx *ctx, const float *xyz, size_t row_
  * then every rank calls comm_init_rank BEFORE set_source.  One RCCL all-reduce of
  * SYMMICP_NSUM doubles per pass. */
 int symmicp_comm_get_unique_id(void *out128);
-/* the contiguous share [begin, begin+count) of n (Morton-sorted) source rows that `rank` of `nranks` owns;
+/* the share of the source `rank` of `nranks` owns: rows [begin, begin+count) of the caller's cloud;
  * pure host arithmetic, the same partition symmicp_set_source applies. */
 int symmicp_shard_range(size_t n, int nranks, int rank, size_t *begin, size_t *count);
 int symmicp_comm_init_rank(symmicp_ctx *ctx, int nranks, int rank, const void *unique_id128);
@@ -215,6 +215,10 @@ typedef struct {
      * kernel_launches[7] counts passes that skipped the tree walk and had to be repaired */
     double kernel_ms[8];
     int64_t kernel_launches[8];
+    /* timing on: duration of each of the first 8 passes since symmicp_reset_stats (pass 0 = the correspondence pass of
+     * symmicp_begin, myicp.cpp:122), and how many passes were timed in all */
+    double pass_ms_head[8];
+    int64_t passes_timed;
 } symmicp_stats;
 int symmicp_get_stats(symmicp_ctx *ctx, symmicp_stats *out);
 int symmicp_reset_stats(symmicp_ctx *ctx);

@@ -130,6 +130,11 @@ def reduce40(p, np_, q, nq, idx=None, pivot=None, max_d2=0.0, min_ndot=-2.0, p2p
     return S
 
 
+def set_threads(n):
+    """threads for the two O(N) loops of an iteration (bench.py's all-core CPU baseline); 1 = the serial reference code"""
+    lib().orc_set_threads(int(n))
+
+
 def solve_quirks_gram(S):
     L = lib()
     S = np.ascontiguousarray(S, np.float64)

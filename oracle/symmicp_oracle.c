@@ -53,6 +53,12 @@
 
 #define ORC_NSUM 40
 
+/* bench.py's all-core CPU baseline: the two O(N) loops of an iteration (exact NN through the grid, the 40-sum reduction)
+ * split over this many threads (OpenMP).  1 (default) = the serial code every parity test runs. */
+static int orc_threads = 1;
+void orc_set_threads(int n) { orc_threads = n > 1 ? n : 1; }
+int orc_get_threads(void) { return orc_threads; }
+
 enum { ORC_MODE_QUIRKS = 0, ORC_MODE_PAPER = 1, ORC_MODE_P2P = 2 };
 enum { ORC_CORR_IDENTITY = 0, ORC_CORR_BRUTE = 1, ORC_CORR_GRID = 2 };
 enum { ORC_SOLVE_GRAM = 0, ORC_SOLVE_LITERAL = 1 };
@@ -161,15 +167,11 @@ void orc_apply(const float X[16], const float *src, float *dst, size_t n, int wi
 /* v=(m,n); [21..26] sum v c; [27..29] sum p; [30..32] sum q;           */
 /* [33] sum |p-q|; [34] count; [35] sum c^2; [36] sum |p-q|^2.          */
 /* ------------------------------------------------------------------ */
-void orc_reduce40(const float *p, const float *np, size_t n_s,
-                  const float *q, const float *nq, size_t n_t,
-                  const int32_t *idx, const float pivot[3], float max_d2, float min_ndot, int p2p, double S[ORC_NSUM])
+static void reduce_range(const float *p, const float *np, size_t i0, size_t i1, const float *q, const float *nq,
+                         const int32_t *idx, const float pv[3], float max_d2, float min_ndot, int p2p, double S[ORC_NSUM])
 {
-    (void)n_t;
     for (int k = 0; k < ORC_NSUM; k++) S[k] = 0.0;
-    float pv[3] = {0, 0, 0};
-    if (pivot) { pv[0] = pivot[0]; pv[1] = pivot[1]; pv[2] = pivot[2]; }
-    for (size_t i = 0; i < n_s; i++) {
+    for (size_t i = i0; i < i1; i++) {
         long j = idx ? (long)idx[i] : (long)i;
         if (j < 0) continue;
         const float *pi = p + 3 * i, *qj = q + 3 * j;
@@ -201,6 +203,24 @@ void orc_reduce40(const float *p, const float *np, size_t n_s,
         if (!p2p) S[35] += (double)c * (double)c;
         S[36] += (double)d2;
     }
+}
+
+void orc_reduce40(const float *p, const float *np, size_t n_s,
+                  const float *q, const float *nq, size_t n_t,
+                  const int32_t *idx, const float pivot[3], float max_d2, float min_ndot, int p2p, double S[ORC_NSUM])
+{
+    (void)n_t;
+    float pv[3] = {0, 0, 0};
+    if (pivot) { pv[0] = pivot[0]; pv[1] = pivot[1]; pv[2] = pivot[2]; }
+    const int T = orc_threads;
+    if (T <= 1) { reduce_range(p, np, 0, n_s, q, nq, idx, pv, max_d2, min_ndot, p2p, S); return; }
+    /* all-core baseline: contiguous chunks, partial records added in chunk order (deterministic for a given thread count) */
+    double *part = (double *)malloc(sizeof(double) * ORC_NSUM * (size_t)T);
+#pragma omp parallel for num_threads(T) schedule(static, 1)
+    for (int t = 0; t < T; t++)
+        reduce_range(p, np, n_s * (size_t)t / (size_t)T, n_s * (size_t)(t + 1) / (size_t)T, q, nq, idx, pv, max_d2, min_ndot, p2p, part + (size_t)t * ORC_NSUM);
+    for (int k = 0; k < ORC_NSUM; k++) { double v = 0.0; for (int t = 0; t < T; t++) v += part[(size_t)t * ORC_NSUM + k]; S[k] = v; }
+    free(part);
 }
 
 /* ------------------------------------------------------------------ */
@@ -639,6 +659,8 @@ void orc_nn_grid(const orc_grid *g, const float X[16], const float *p, size_t n_
                  int32_t *idx, float *d2_out)
 {
     int maxdim = g->dim[0] > g->dim[1] ? g->dim[0] : g->dim[1]; if (g->dim[2] > maxdim) maxdim = g->dim[2];
+    /* queries are independent: the all-core baseline splits them over threads (results identical to the serial loop) */
+#pragma omp parallel for num_threads(orc_threads) schedule(dynamic, 4096) if (orc_threads > 1)
     for (size_t i = 0; i < n_s; i++) {
         float pt[3];
         if (X) xform_pt(X, p + 3 * i, pt, 1); else { pt[0] = p[3 * i]; pt[1] = p[3 * i + 1]; pt[2] = p[3 * i + 2]; }

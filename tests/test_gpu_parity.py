@@ -531,7 +531,7 @@ def test_rccl_path_single_rank_communicator(sym, cat, monkeypatch):
 @pytest.mark.parametrize("world", [2, 5])
 def test_sharded_ranks_with_external_exchange(sym, oracle, world):
     """The sharded engine itself, every rank of it, on this one GPU: `world` contexts in external-exchange mode (each
-    keeps its contiguous share of the Morton-sorted source, the target is replicated), the test playing the all-reduce.
+    keeps its contiguous share of the source rows, Morton-sorted on its own; the target is replicated), the test playing the all-reduce.
     The records must add up to the unsharded record, the shards' pairs must tile the unsharded pairs, every rank must
     compute the same 4x4, and that 4x4 must follow the unsharded run."""
     from symmicp import synth
@@ -565,6 +565,8 @@ def test_sharded_ranks_with_external_exchange(sym, oracle, world):
         for e in engs:
             i_r, d_r = e.correspondences()
             m = i_r >= 0
+            # a rank owns (uploads, sorts, searches) exactly the rows [offset, offset + count) of the caller's cloud
+            assert np.array_equal(np.flatnonzero(m), np.arange(e.local_offset(), e.local_offset() + e.local_count()))
             owned += m
             idx[m] = i_r[m]; d2[m] = d_r[m]
         assert np.all(owned == 1)
@@ -615,8 +617,31 @@ def test_bench_line_keeps_its_contract():
     assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-4
     assert abs(rf["achieved"] - rf["algorithmic_bytes_per_launch"] / (rf["kernel_ms"] * 1e-3) / 1e9) < 1e-2 * rf["achieved"]
+    assert rf["traffic"] is None or rf["traffic_source"]          # PMC traffic is a committed profile, labelled as such
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0 and cb["unit"] == "iter/s" and cb["sample"]
+    # what the reference itself costs (identity pairing + literal N x 3 SVD solves) and the all-core like-for-like figure
+    assert cb["reference_faithful"]["value"] > 0 and cb["reference_faithful"]["cores"] == 1
+    assert cb["all_cores"]["value"] > 0 and cb["all_cores"]["cores"] == os.cpu_count()
+    # what was measured: pass durations by regime, the cold exact-NN rate, each regime against the resource that bounds it
+    ps = d["passes"]
+    assert ps["first_ms"] > 0 and len(ps["second_third_ms"]) == 2 and ps["converged_ms"] > 0 and ps["timed"] == 7 and ps["loop"] in ("device", "host")
+    assert abs(d["mcorr_per_sec_first_pass"] - 20000 / (ps["first_ms"] * 1e-3) / 1e6) < 1e-2 * d["mcorr_per_sec_first_pass"]
+    rr = d["roofline_by_regime"]
+    assert [e["bound"] for e in rr] == ["valu", "valu", "hbm"] and all(e["kernel"] and e["model"] and e["ms"] > 0 for e in rr)
+    assert abs(rr[2]["frac"] - rr[2]["achieved"] / 8000.0) < 1e-3
+
+
+def test_bench_brute_force_is_priced_against_vector_issue():
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--points", "20000", "--steps", "3", "--warmup", "1", "--corr", "brute",
+                        "--workload", "c3", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    e = d["roofline_by_regime"][0]
+    assert e["bound"] == "valu" and e["kernel"] == "k_nn_brute" and 0 < e["frac"] < 1 and e["peak"] == 1228.8
 
 
 def test_bench_multi_rank_scaffolding_on_one_gpu():
@@ -640,6 +665,11 @@ def test_bench_multi_rank_scaffolding_on_one_gpu():
     assert d["n_gpus"] == 2 and d["steps"] == 6 and d["value"] > 0 and d["cpu_baseline"] is None
     assert d["final_transform_max_abs_err_vs_truth"] < 5e-3        # 6 iterations on a 30k-point pair: on its way to the truth
     assert "x2" in d["config"]["parallelism"]
+    # N > 1: which exchange ran, and per-rank figures to diagnose a scaling curve with
+    assert d["exchange"] == "torch" and d["exchange_requested"] == "torch" and d["exchange_fallback"] is False
+    pr = d["per_rank"]
+    assert [p["rank"] for p in pr] == [0, 1] and sum(p["n_loc"] for p in pr) == 30000
+    assert all(p["first_pass_ms"] > 0 and p["pass_ms"] > 0 and p["set_source_ms"] > 0 and p["kernels_host_loop"] for p in pr)
 
 
 def test_rccl_bootstrap_between_two_ranks_reaches_the_device_check():
@@ -663,6 +693,26 @@ def test_rccl_bootstrap_between_two_ranks_reaches_the_device_check():
     import json
     d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
     assert d["n_gpus"] == 2 and "shared-memory" in d["config"]["parallelism"]
+    assert d["exchange"] == "shm" and d["exchange_requested"] == "rccl" and d["exchange_fallback"] is True and "ncclCommInitRank" in d["exchange_fallback_reason"]
+
+
+def test_bench_falls_back_when_rank0_cannot_even_load_rccl():
+    """The other failure of the fallback: rank 0 has no unique id to broadcast (librccl missing).  Every rank must still take
+    part in the same collectives -- rank 0 broadcasts None, nobody builds a communicator, all agree on the shared-memory
+    exchange -- instead of rank 0 running ahead into a different collective."""
+    import json
+    import socket
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, SYMMICP_BENCH_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0", SYMMICP_BENCH_FAIL_UID="1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1",
+                        "--points", "20000", "--exchange", "rccl", "--dist-backend", "gloo", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=300, cwd=root, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert d["exchange"] == "shm" and d["exchange_fallback"] is True and "no unique id" in d["exchange_fallback_reason"]
 
 
 def _shm_rank(rank, world, job, outdir):
