@@ -94,7 +94,10 @@ def main():
 
     # ---- data (every rank regenerates the same bits) ----------------------------------------------
     gen = dict(c3=synth.c3_uniform, c4=synth.c4_surface, c5=synth.c5_scan)[args.workload]
-    d = gen(args.points)
+    if args.workload == "c5":      # the ray casting of a large scan is spread over this rank's share of the host's cores
+        d = gen(args.points, workers=max(1, min(16, (os.cpu_count() or 1) // max(1, world))) if args.points >= 1_000_000 else 1)
+    else:
+        d = gen(args.points)
     n_s, n_t = d["src"].shape[0], d["tgt"].shape[0]
     K, W = args.steps, args.warmup
 

@@ -515,8 +515,8 @@ static int build_octree(symmicp_ctx *c, const uint32_t *keys, const float4 *tq, 
     }
     ix->olevel_off[NL] = (uint32_t)total;
     for (int l = 0; l < NL; l++)
-        // child_first is a 24-bit field (node word and walk stack word): targets beyond ~16.7M distinct finest cells are refused
-        if (cnt[l] > 0xFFFFFFu) return fail(c, SYMMICP_ERR_SIZE, "octree level exceeds 2^24 nodes (target cloud too large for SYMMICP_CORR_TREE)");
+        // child_first is a 28-bit field of the node word: targets beyond ~268M distinct finest cells are refused
+        if (cnt[l] > kOctCfMask) return fail(c, SYMMICP_ERR_SIZE, "octree level exceeds 2^28 nodes (target cloud too large for SYMMICP_CORR_TREE)");
     HIP_TRY(c, first.alloc_temp(c->arena, total + 1));
     HIP_TRY(c, keep_alloc(c, (void **)&nodes, sizeof(float4) * 2 * total));
     for (int l = 0; l < NL; l++)
@@ -1107,50 +1107,67 @@ static int run_batch(symmicp_ctx *c, int want, float *diffs_before, int *n_done,
     }
     c->pass_blocks = blocks;
     uint32_t *counters = tree ? c->wl_count : nullptr;
-    // the record of the last complete pass is in d_sums: solve from it, then `want` x (pass, reduce, [all-reduce,] solve)
-    launch_reduce_solve(c->partials, blocks, c->d_sums, 2, c->d_loop, lc, c->h_ring_dev, symmicp_ctx::kRing, counters, c->stream);
-    for (int p = 0; p < want; p++) {
-        hipEvent_t *ev = nullptr;
-        if (c->timing == 1) {
-            if (c->ev_used == symmicp_ctx::kEvRing) flush_events(c);
-            ev = c->ev + c->ev_used * symmicp_ctx::kEvPer;
-            c->ev_split[c->ev_used] = 1;
-            hipEventRecord(ev[0], c->stream);
-        }
-        if (tree) launch_pass_fused(a, c->ix, c->wl, blocks, c->stream);
-        else launch_pass_identity(a, c->tgt, blocks, vec4, c->stream);
-        if (ev) { hipEventRecord(ev[4], c->stream); c->ev_used++; }
-        if (c->comm || blocks > 512) {
-            // sharded: the record is summed over the ranks before the solve; many partial records (an 8M-point identity pass):
-            // the 40-block reduce is faster than one block's
-            launch_final_reduce(c->partials, blocks, c->d_sums, nullptr, c->ticket, 0ull, counters, 0, c->stream);
-            if (c->comm) {
-                int r = g_rccl.AllReduce(c->d_sums, c->d_sums, kNSum, kNcclFloat64, kNcclSum, c->comm, c->stream);
-                if (r != 0) return fail(c, SYMMICP_ERR_COMM, std::string("ncclAllReduce: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?"));
+    // The record of the last complete pass is in d_sums: solve from it, then (pass, reduce, [all-reduce,] solve) per iteration.
+    // Passes are enqueued in chunks of 4, 8, 16, ... with one look at the loop state between chunks: a loop that stops early
+    // (convergence, a pass that has to be redone) leaves at most one chunk of no-op launches behind.
+    if (c->timing == 1 && c->ev_used + want > symmicp_ctx::kEvRing) flush_events(c);
+    int enq = 0, chunk = 4;
+    bool first_chunk = true;
+    while (enq < want) {
+        const int nq = (want - enq < chunk) ? want - enq : chunk;
+        const int it_before = first_chunk ? it0 : c->h_loop->iters;
+        const int ev_used0 = c->ev_used;
+        if (first_chunk) launch_reduce_solve(c->partials, blocks, c->d_sums, 2, c->d_loop, lc, c->h_ring_dev, symmicp_ctx::kRing, counters, c->stream);
+        for (int p = 0; p < nq; p++) {
+            hipEvent_t *ev = nullptr;
+            if (c->timing == 1 && c->ev_used < symmicp_ctx::kEvRing) {
+                ev = c->ev + c->ev_used * symmicp_ctx::kEvPer;
+                c->ev_split[c->ev_used] = 1;
+                hipEventRecord(ev[0], c->stream);
             }
-            launch_reduce_solve(c->partials, blocks, c->d_sums, 1, c->d_loop, lc, c->h_ring_dev, symmicp_ctx::kRing, counters, c->stream);
-        } else {
-            launch_reduce_solve(c->partials, blocks, c->d_sums, 0, c->d_loop, lc, c->h_ring_dev, symmicp_ctx::kRing, counters, c->stream);
+            if (tree) launch_pass_fused(a, c->ix, c->wl, blocks, c->stream);
+            else launch_pass_identity(a, c->tgt, blocks, vec4, c->stream);
+            if (ev) { hipEventRecord(ev[4], c->stream); c->ev_used++; }
+            if (c->comm || blocks > 512) {
+                // sharded: the record is summed over the ranks before the solve; many partial records (an 8M-point identity pass):
+                // the 40-block reduce is faster than one block's
+                launch_final_reduce(c->partials, blocks, c->d_sums, nullptr, c->ticket, 0ull, counters, 0, c->stream);
+                if (c->comm) {
+                    int r = g_rccl.AllReduce(c->d_sums, c->d_sums, kNSum, kNcclFloat64, kNcclSum, c->comm, c->stream);
+                    if (r != 0) return fail(c, SYMMICP_ERR_COMM, std::string("ncclAllReduce: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?"));
+                }
+                launch_reduce_solve(c->partials, blocks, c->d_sums, 1, c->d_loop, lc, c->h_ring_dev, symmicp_ctx::kRing, counters, c->stream);
+            } else {
+                launch_reduce_solve(c->partials, blocks, c->d_sums, 0, c->d_loop, lc, c->h_ring_dev, symmicp_ctx::kRing, counters, c->stream);
+            }
         }
-    }
-    const unsigned long long seq = ++c->batch_seq;
-    launch_loop_end(c->d_loop, c->h_loop_dev, c->h_done_dev, seq, c->stream);
-    volatile unsigned long long *flag = reinterpret_cast<volatile unsigned long long *>(c->h_done);
-    const double t_spin = now_s();
-    unsigned spins = 0;
-    bool got = false;
-    while (!(got = (*flag == seq))) {
-        __builtin_ia32_pause();
-        if ((++spins & 0xFFFu) == 0) {
-            if (hipStreamQuery(c->stream) != hipErrorNotReady) { got = (*flag == seq); break; }
-            if (now_s() - t_spin > 60.0) break;
+        const unsigned long long seq = ++c->batch_seq;
+        launch_loop_end(c->d_loop, c->h_loop_dev, c->h_done_dev, seq, c->stream);
+        volatile unsigned long long *flag = reinterpret_cast<volatile unsigned long long *>(c->h_done);
+        const double t_spin = now_s();
+        unsigned spins = 0;
+        bool got = false;
+        while (!(got = (*flag == seq))) {
+            __builtin_ia32_pause();
+            if ((++spins & 0xFFFu) == 0) {
+                if (hipStreamQuery(c->stream) != hipErrorNotReady) { got = (*flag == seq); break; }
+                if (now_s() - t_spin > 60.0) break;
+            }
         }
-    }
-    __atomic_thread_fence(__ATOMIC_ACQUIRE);
-    if (!got) {
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
-        HIP_TRY(c, hipGetLastError());
-        if (*flag != seq) return fail(c, SYMMICP_ERR_HIP, "batch finished without publishing its end flag");
+        __atomic_thread_fence(__ATOMIC_ACQUIRE);
+        if (!got) {
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            HIP_TRY(c, hipGetLastError());
+            if (*flag != seq) return fail(c, SYMMICP_ERR_HIP, "batch finished without publishing its end flag");
+        }
+        enq += nq;
+        first_chunk = false;
+        // passes of this chunk that did run (a pass that has to be redone ran too); the events of the no-op launches behind a
+        // stop are dropped
+        const int ran = (c->h_loop->iters - it_before) + (c->h_loop->reason == LOOP_REDO_PASS ? 1 : 0);
+        if (c->timing == 1 && ran >= 0 && ev_used0 + ran < c->ev_used) c->ev_used = ev_used0 + ran;
+        if (c->h_loop->stop) break;
+        chunk *= 2;
     }
     const LoopState &hl = *c->h_loop;
     const int it1 = hl.iters;                         // passes complete
@@ -1168,7 +1185,7 @@ static int run_batch(symmicp_ctx *c, int want, float *diffs_before, int *n_done,
     *n_done = it1 - it0;
     *small_step = hl.reason == LOOP_DONE && hl.small_step != 0;
     if (tree && it1 > it0) c->last_uncertified = c->h_ring[it1 % symmicp_ctx::kRing].pad;
-    if (std::getenv("SYMMICP_DEBUG_HOST")) std::fprintf(stderr, "[symmicp host] batch: %d of %d passes on the device, reason %d\n", it1 - it0, want, hl.reason);
+    if (std::getenv("SYMMICP_DEBUG_HOST")) std::fprintf(stderr, "[symmicp host] batch: %d of %d passes on the device (%d enqueued), reason %d\n", it1 - it0, want, enq, hl.reason);
     if (hl.reason == LOOP_SLOW) c->host_passes_since_bailout = 1;      // one host pass, then look again
     if (hl.reason == LOOP_REDO_PASS || hl.reason == LOOP_HOST_SOLVE) {
         c->host_passes_since_bailout = 0;

@@ -381,7 +381,7 @@ __global__ __launch_bounds__(256) void k_oct_nodes(int level, const float4 *__re
             lo.x = fminf(lo.x, q.x); lo.y = fminf(lo.y, q.y); lo.z = fminf(lo.z, q.z);
             hi.x = fmaxf(hi.x, q.x); hi.y = fmaxf(hi.y, q.y); hi.z = fmaxf(hi.z, q.z);
         }
-        packed = npts & 0xFFFFFFu;                  // leaf: nchild = 0
+        packed = npts & kOctCfMask;                 // leaf: nchild = 0
     } else {
         const uint32_t c0 = nid_next[p0];
         const uint32_t c1 = (id + 1 < n_nodes) ? nid_next[p1] : n_nodes_next;
@@ -390,7 +390,7 @@ __global__ __launch_bounds__(256) void k_oct_nodes(int level, const float4 *__re
             lo.x = fminf(lo.x, a.x); lo.y = fminf(lo.y, a.y); lo.z = fminf(lo.z, a.z);
             hi.x = fmaxf(hi.x, b.x); hi.y = fmaxf(hi.y, b.y); hi.z = fmaxf(hi.z, b.z);
         }
-        packed = (c0 & 0xFFFFFFu) | ((c1 - c0) << 24);
+        packed = (c0 & kOctCfMask) | ((c1 - c0) << 28);
     }
     lo.w = __int_as_float((int)p0);
     hi.w = __int_as_float((int)packed);

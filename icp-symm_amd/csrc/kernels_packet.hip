@@ -204,7 +204,7 @@ struct PktCounters {
 
 template <bool CERT>
 __device__ __noinline__ void pkt_dfs(const float4 *__restrict__ onodes, const float4 *__restrict__ tq, const uint32_t *s_off, float4 (*stk)[2],
-                                     const float (*s_sb)[8], float px, float py, float pz, PktBest &b, float &thr, float pad, PktCounters &cn)
+                                     const float (*s_sb)[8], uint8_t *s_lvl, float px, float py, float pz, PktBest &b, float &thr, float pad, PktCounters &cn)
 {
     const int lane = threadIdx.x;
     const int sub = lane & 3, chl = lane >> 2;                          // lane 4c+g = (child c, sub-group g)
@@ -212,7 +212,8 @@ __device__ __noinline__ void pkt_dfs(const float4 *__restrict__ onodes, const fl
     const float4 sblo = *reinterpret_cast<const float4 *>(&s_sb[sub][0]), sbhi = *reinterpret_cast<const float4 *>(&s_sb[sub][4]);
     if (lane == 0) {
         const float4 rA = onodes[0], rB = onodes[1];
-        stk[0][0] = rA; stk[0][1] = rB;                                 // level 0 in bits 28..31 of the packed word: already 0
+        stk[0][0] = rA; stk[0][1] = rB;
+        s_lvl[0] = 0;                                                   // the level of every stacked node rides beside it
     }
     int sp = 1;
     __builtin_amdgcn_wave_barrier();
@@ -223,7 +224,7 @@ __device__ __noinline__ void pkt_dfs(const float4 *__restrict__ onodes, const fl
         if (__ballot(want) == 0ull) { cn.rejected++; continue; }
         const uint32_t first = (uint32_t)__builtin_amdgcn_readfirstlane(__float_as_int(nA.w));
         const uint32_t packed = (uint32_t)__builtin_amdgcn_readfirstlane(__float_as_int(nB.w));
-        const uint32_t level = packed >> 28, nch = (packed >> 24) & 15u, cf = packed & 0xFFFFFFu;
+        const uint32_t level = s_lvl[sp], nch = oct_nch(packed), cf = oct_cf(packed);
         if (nch == 0) {
             cn.leaves++; cn.points += cf;
             pkt_leaf_scalar<CERT>(tq, first, cf, px, py, pz, b, cn.ties);
@@ -260,8 +261,8 @@ __device__ __noinline__ void pkt_dfs(const float4 *__restrict__ onodes, const fl
                 const uint32_t rmin = (uint32_t)__popc(mc & ((1u << (4 * cmin)) - 1u));
                 if (mine && sub == 0 && ((mc >> (4 * (chl & 7))) & 1u)) {
                     const uint32_t slot = ((uint32_t)chl == cmin) ? nk - 1u : (rank > rmin ? rank - 1u : rank);
-                    cB.w = __int_as_float((int)(((uint32_t)__float_as_int(cB.w) & 0x0FFFFFFFu) | ((level + 1u) << 28)));
                     stk[sp + slot][0] = cA; stk[sp + slot][1] = cB;
+                    s_lvl[sp + slot] = (uint8_t)(level + 1u);
                 }
                 sp += (int)nk;
             }
@@ -286,6 +287,7 @@ __global__ __launch_bounds__(64, PKT_WAVES) void k_search_packet(PassArgs a, Tar
 {
     __shared__ float4 s_buf[kPktStack][2];         // BFS: two frontier buffers; DFS fallback: the stack
     __shared__ float s_sb[4][8];                   // bounding boxes of the four 16-query sub-groups
+    __shared__ uint8_t s_lvl[kPktStack];           // DFS fallback: level of each stacked node
     __shared__ uint32_t s_off[kMortonBits + 2];
     uint32_t (*fr)[kFrontCap] = reinterpret_cast<uint32_t (*)[kFrontCap]>(&s_buf[0][0]);
     const int lane = threadIdx.x;
@@ -342,8 +344,8 @@ __global__ __launch_bounds__(64, PKT_WAVES) void k_search_packet(PassArgs a, Tar
                 const int mid = (wants0 >> 32) & 1ull ? 32 : (int)__ffsll((long long)wants0) - 1;
                 const float cx = bcast(px, mid), cy = bcast(py, mid), cz = bcast(pz, mid);
                 uint32_t packed = root_packed, first = root_first, level = 0;
-                while (((packed >> 24) & 15u) != 0u) {
-                    const uint32_t nch = (packed >> 24) & 15u, cf = packed & 0xFFFFFFu;
+                while (oct_nch(packed) != 0u) {
+                    const uint32_t nch = oct_nch(packed), cf = oct_cf(packed);
                     uint32_t key = 0xFFFFFFFFu;
                     float4 cA = make_float4(0.f, 0.f, 0.f, 0.f), cB = cA;
                     if ((uint32_t)lane < nch) {
@@ -358,7 +360,7 @@ __global__ __launch_bounds__(64, PKT_WAVES) void k_search_packet(PassArgs a, Tar
                     level++;
                     if (DBG) cn.steps++;
                 }
-                const uint32_t cnt = packed & 0xFFFFFFu;
+                const uint32_t cnt = oct_cf(packed);
                 if (DBG) cn.points += cnt;
                 pkt_leaf_scalar<CERT>(tq, first, cnt, px, py, pz, b, cn.ties);
                 thr = fminf(thr, pkt_threshold(b.d2, pad));
@@ -368,12 +370,12 @@ __global__ __launch_bounds__(64, PKT_WAVES) void k_search_packet(PassArgs a, Tar
             // ---- breadth-first sweep
             uint32_t nf = 0;
             int cur = 0;
-            if (!done && ((root_packed >> 24) & 15u) != 0u) {
-                if (lane == 0) fr[0][0] = root_packed & 0x0FFFFFFFu;
+            if (!done && oct_nch(root_packed) != 0u) {
+                if (lane == 0) fr[0][0] = root_packed;
                 nf = 1;
             } else if (!done) {
                 // the root is a leaf and there was no dive
-                pkt_leaf_scalar<CERT>(tq, root_first, root_packed & 0xFFFFFFu, px, py, pz, b, cn.ties);
+                pkt_leaf_scalar<CERT>(tq, root_first, oct_cf(root_packed), px, py, pz, b, cn.ties);
                 thr = fminf(thr, pkt_threshold(b.d2, pad));
             }
             __builtin_amdgcn_wave_barrier();
@@ -392,11 +394,11 @@ __global__ __launch_bounds__(64, PKT_WAVES) void k_search_packet(PassArgs a, Tar
                     if (DBG) { cn.steps++; steps_pk++; }
                     const uint32_t f = f0 + (uint32_t)(lane >> 3), c = (uint32_t)(lane & 7);
                     const uint32_t pkd = (f < nf) ? fr[cur][f] : 0u;
-                    const bool valid = c < ((pkd >> 24) & 15u);
+                    const bool valid = c < oct_nch(pkd);
                     float4 cA = make_float4(0.f, 0.f, 0.f, 0.f), cB = cA;
                     bool keep = false;
                     if (valid) {
-                        const float4 *__restrict__ ch = onodes + 2 * ((size_t)off_next + (pkd & 0xFFFFFFu) + c);
+                        const float4 *__restrict__ ch = onodes + 2 * ((size_t)off_next + oct_cf(pkd) + c);
                         cA = ch[0]; cB = ch[1];
 #pragma unroll
                         for (int g = 0; g < 4; g++) {
@@ -408,14 +410,14 @@ __global__ __launch_bounds__(64, PKT_WAVES) void k_search_packet(PassArgs a, Tar
                         }
                     }
                     const uint32_t cpk = (uint32_t)__float_as_int(cB.w);
-                    const bool isleaf = ((cpk >> 24) & 15u) == 0u;
+                    const bool isleaf = oct_nch(cpk) == 0u;
                     const bool keepL = keep && isleaf, keepI = keep && !isleaf;
                     if (DBG) cn.nodes += (unsigned long long)__popcll(__ballot(valid));
                     // internal survivors -> next frontier
                     const unsigned long long mI = __ballot(keepI);
                     if (mI) {
                         const uint32_t slot = nn + __builtin_amdgcn_mbcnt_hi((uint32_t)(mI >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mI, 0u));
-                        if (keepI && slot < (uint32_t)kFrontCap) fr[cur ^ 1][slot] = cpk & 0x0FFFFFFFu;
+                        if (keepI && slot < (uint32_t)kFrontCap) fr[cur ^ 1][slot] = cpk;
                         nn += (uint32_t)__popcll(mI);
                     }
                     // leaf survivors: their lanes fetch the points (all leaves of the step at once), then one leaf at a time
@@ -438,7 +440,7 @@ __global__ __launch_bounds__(64, PKT_WAVES) void k_search_packet(PassArgs a, Tar
                             lo.x = bcast(cA.x, src); lo.y = bcast(cA.y, src); lo.z = bcast(cA.z, src);
                             hi.x = bcast(cB.x, src); hi.y = bcast(cB.y, src); hi.z = bcast(cB.z, src);
                             if (__ballot(boxdist2(px, py, pz, lo, hi) <= thr) == 0ull) { if (DBG) cn.rejected++; continue; }
-                            const uint32_t cnt = (uint32_t)__builtin_amdgcn_readlane((int)cpk, src) & 0xFFFFFFu;
+                            const uint32_t cnt = oct_cf((uint32_t)__builtin_amdgcn_readlane((int)cpk, src));
                             if (DBG) cn.points += cnt;
                             pkt_leaf_regs<CERT>(tq, pt, src, first, min(cnt, 8u), px, py, pz, b, cn.ties);
                             if (cnt > 8u) pkt_leaf_scalar<CERT>(tq, first + 8u, cnt - 8u, px, py, pz, b, cn.ties);
@@ -462,7 +464,7 @@ __global__ __launch_bounds__(64, PKT_WAVES) void k_search_packet(PassArgs a, Tar
                 // a frontier outgrew its LDS slot: finish depth-first from the root with the bounds reached so far (exact)
                 cn.overflow++;
                 ovf_pk = true;
-                pkt_dfs<CERT>(onodes, tq, s_off, s_buf, s_sb, px, py, pz, b, thr, pad, cn);
+                pkt_dfs<CERT>(onodes, tq, s_off, s_buf, s_sb, s_lvl, px, py, pz, b, thr, pad, cn);
             }
         }
         if (active) {

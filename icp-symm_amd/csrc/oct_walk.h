@@ -31,21 +31,29 @@ __device__ __forceinline__ void test_point(Best &b, const float4 &q, int32_t pos
 // an internal node loads its <= 8 child boxes (contiguous in the next level), enters the nearest one that can still
 // win and remembers the others as (child_first << 8 | 8-bit mask) in a register stack, one word per level.  Coming
 // back to a sibling, its box is tested again against the (now smaller) best.
+// one word per level: (low 24 bits of child_first) << 8 | 8-bit mask of the siblings still to visit; the top 4 bits of the
+// 28-bit child_first ride in a 64-bit shift register of nibbles (two registers instead of one more word per level: the walk
+// kernel is register-bound)
 struct OctStack {
     uint32_t s[kMortonBits];
-    __device__ __forceinline__ void push(uint32_t w)
+    unsigned long long hi;
+    __device__ __forceinline__ void push(uint32_t cf, uint32_t mask)
     {
 #pragma unroll
         for (int k = kMortonBits - 1; k > 0; k--) s[k] = s[k - 1];
-        s[0] = w;
+        s[0] = ((cf & 0xFFFFFFu) << 8) | mask;
+        hi = (hi << 4) | (unsigned long long)(cf >> 24);
     }
     __device__ __forceinline__ void pop()
     {
 #pragma unroll
         for (int k = 0; k < kMortonBits - 1; k++) s[k] = s[k + 1];
         s[kMortonBits - 1] = 0;
+        hi >>= 4;
     }
+    __device__ __forceinline__ uint32_t top_cf() const { return (s[0] >> 8) | ((uint32_t)(hi & 0xFull) << 24); }
 };
+static_assert(kMortonBits * 4 <= 64, "nibble register too short for the octree depth");
 
 // One loop iteration = one node visit, and a leaf is visited with the SAME code as an internal node: its points
 // are read as degenerate boxes (lo = hi = point), for which boxdist2 is bit-for-bit dist2.  Lanes of a wave sit at
@@ -61,6 +69,7 @@ __device__ __forceinline__ uint32_t oct_walk(const TargetIndex &ix, float px, fl
     OctStack st;
 #pragma unroll
     for (int k = 0; k < kMortonBits; k++) st.s[k] = 0;
+    st.hi = 0;
     int L = 0;
     uint32_t idx = 0;
     uint32_t visits = 0;
@@ -74,9 +83,9 @@ __device__ __forceinline__ uint32_t oct_walk(const TargetIndex &ix, float px, fl
         // the header is the node's own box: a sibling taken from the pending list is re-tested here against the
         // current best, so the list pop below needs no loads of its own
         const bool alive = boxdist2(px, py, pz, hA, hB) <= b.d2;
-        const uint32_t nch = packed >> 24;
+        const uint32_t nch = oct_nch(packed);
         const bool leaf = (nch == 0);
-        const uint32_t cf = packed & 0xFFFFFFu;                 // internal: first child; leaf: number of points
+        const uint32_t cf = oct_cf(packed);                     // internal: first child; leaf: number of points
         const uint32_t total = alive ? (leaf ? cf : nch) : 0u;
         // entity e of this node: leaf -> point tq[first + e] ; internal -> child box onodes[level L+1][cf + e]
         const float4 *__restrict__ ent = leaf ? (ix.tq + first) : (ix.onodes + 2 * ((size_t)ix.olevel_off[L + 1] + cf));
@@ -116,7 +125,7 @@ __device__ __forceinline__ uint32_t oct_walk(const TargetIndex &ix, float px, fl
             if (leaf) {
                 if (ed <= b.d2 && (ed < b.d2 || erow < b.row)) { b.d2 = ed; b.row = erow; b.pos = (int32_t)(first + e0 + min((uint32_t)ec, last)); }
             } else if (mask) {
-                st.push((cf << 8) | (mask & ~(1u << ec)));
+                st.push(cf, mask & ~(1u << ec));
                 L++;
                 idx = cf + (uint32_t)ec;
                 descended = true;
@@ -131,7 +140,7 @@ __device__ __forceinline__ uint32_t oct_walk(const TargetIndex &ix, float px, fl
             if (mask == 0) { st.pop(); L--; continue; }
             const int c = __ffs((int)mask) - 1;
             st.s[0] = w & ~(1u << c);
-            idx = (w >> 8) + (uint32_t)c;
+            idx = st.top_cf() + (uint32_t)c;
             found = true;
             break;
         }

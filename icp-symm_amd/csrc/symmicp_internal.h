@@ -59,13 +59,18 @@ struct TargetIndex {
     // sparse octree over the same sorted points: node = one Morton prefix (an octree cell that holds points),
     // levels 0 (root) .. kMortonBits.  Two float4 per node:
     //   A = (lo.x, lo.y, lo.z, first point as int bits)
-    //   B = (hi.x, hi.y, hi.z, packed)   packed = child_first (24 bits, index within the next level) | nchild << 24 ;
-    //                                     nchild == 0 marks a leaf, whose low 24 bits hold its point count
+    //   B = (hi.x, hi.y, hi.z, packed)   packed = child_first (28 bits, index within the next level) | nchild << 28 ;
+    //                                     nchild == 0 marks a leaf, whose low 28 bits hold its point count
+    //                                     (oct_nch / oct_cf below; 2^28 nodes per level: targets of ~250M points)
     // Sibling cells are disjoint, so box distances discriminate at every level (unlike runs of the sorted order,
     // whose boxes straddle the big jumps of the Z curve).
     const float4 *onodes;
     uint32_t olevel_off[kMortonBits + 2];
 };
+
+constexpr uint32_t kOctCfMask = 0x0FFFFFFFu;
+__host__ __device__ inline uint32_t oct_nch(uint32_t packed) { return packed >> 28; }
+__host__ __device__ inline uint32_t oct_cf(uint32_t packed) { return packed & kOctCfMask; }
 
 // Append lists for queries a kernel hands to a later kernel of the same pass.  One returning atomic on a single
 // word tops out near 88 per microsecond chip-wide, so a list is 64 shards (counter words 64 B apart); a producer

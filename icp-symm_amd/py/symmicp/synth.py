@@ -23,18 +23,18 @@ def _mix64(z):
     return z
 
 
-def splitmix64(seed, n, stream=0):
-    """n uint64 values.  (seed, stream) is hashed into a base first, so neighbouring seeds or streams
-    give unrelated sequences; value i = mix64(base + (i+1) * golden)."""
+def splitmix64(seed, n, stream=0, first=0):
+    """n uint64 values, numbers first .. first+n-1 of the sequence.  (seed, stream) is hashed into a base first, so
+    neighbouring seeds or streams give unrelated sequences; value i = mix64(base + (i+1) * golden)."""
     with np.errstate(over="ignore"):
         base = _mix64(np.array([np.uint64(seed) * np.uint64(0x9E3779B97F4A7C15) + np.uint64(stream) * np.uint64(0xD1B54A32D192ED03) + np.uint64(0x2545F4914F6CDD1D)], np.uint64))[0]
-        z = base + np.arange(1, n + 1, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15)
+        z = base + np.arange(first + 1, first + n + 1, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15)
     return _mix64(z)
 
 
-def uniform01(seed, n, stream=0):
+def uniform01(seed, n, stream=0, first=0):
     """float64 in [0,1) with 53 random bits"""
-    return (splitmix64(seed, n, stream) >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)
+    return (splitmix64(seed, n, stream, first) >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)
 
 
 def rotation(deg, axis):
@@ -135,26 +135,49 @@ def _scan_normals(p):
     return n / np.linalg.norm(n, axis=1, keepdims=True)
 
 
-def c5_scan(n=8_000_000, seed=0xC5, rings=64):
+def _c5_sweep_chunk(args):
+    """rays i0 .. i1-1 of one sweep (ray i depends on i alone: chunks can be cast on separate cores)"""
+    sd, phase, per, rings, i0, i1 = args
+    cnt = i1 - i0
+    idx = np.arange(i0, i1)
+    ring, az_idx = idx // per, idx % per
+    origin = np.array([0.5, 0.5, 1.2])
+    az = 2 * np.pi * (az_idx + phase + 0.3 * uniform01(sd, cnt, 0, i0)) / per
+    polar = np.deg2rad(5.0 + 35.0 * (ring + uniform01(sd, cnt, 1, i0)) / rings)
+    d = np.stack([np.sin(polar) * np.cos(az), np.sin(polar) * np.sin(az), -np.cos(polar)], 1)
+    s = _raycast(origin, d)
+    clean = origin + d * s[:, None]
+    noise = 1e-3 * np.sqrt(-2 * np.log(1 - uniform01(sd, cnt, 2, i0))) * np.cos(2 * np.pi * uniform01(sd, cnt, 3, i0))
+    return origin + d * (s + noise)[:, None], _scan_normals(clean)
+
+
+def c5_scan(n=8_000_000, seed=0xC5, rings=64, workers=None):
     """C5, scan-like: a sensor 1.2 above the (periodically extended) C4 height field sweeps `rings`
     cones (5..40 deg off nadir) x n/rings azimuth samples; rays are cast onto the surface, which is
     clipped from below by a ground plane; range noise sigma = 1e-3.  Inner rings are much denser than
     outer ones (same sample count on a smaller circle), as in a real sweep.  The target is the same
-    sweep half an azimuth step later (different sample points) moved by 2 deg + small t."""
+    sweep half an azimuth step later (different sample points) moved by 2 deg + small t.
+    Large clouds are cast in chunks on up to `workers` processes (default: the host's cores, at most 32); the result
+    does not depend on the chunking."""
+    import os
     per = n // rings
     n = per * rings
-    origin = np.array([0.5, 0.5, 1.2])
-    ring = np.repeat(np.arange(rings), per)
-    az_idx = np.tile(np.arange(per), rings)
+    if workers is None:
+        workers = min(32, os.cpu_count() or 1) if n >= 1_000_000 else 1
+    nchunk = max(1, min(4 * workers, n // 65536)) if workers > 1 else 1
+    edges = [n * k // nchunk for k in range(nchunk + 1)]
 
     def sweep(sd, phase):
-        az = 2 * np.pi * (az_idx + phase + 0.3 * uniform01(sd, n, 0)) / per
-        polar = np.deg2rad(5.0 + 35.0 * (ring + uniform01(sd, n, 1)) / rings)
-        d = np.stack([np.sin(polar) * np.cos(az), np.sin(polar) * np.sin(az), -np.cos(polar)], 1)
-        s = _raycast(origin, d)
-        clean = origin + d * s[:, None]
-        noise = 1e-3 * np.sqrt(-2 * np.log(1 - uniform01(sd, n, 2))) * np.cos(2 * np.pi * uniform01(sd, n, 3))
-        return origin + d * (s + noise)[:, None], _scan_normals(clean)
+        jobs = [(sd, phase, per, rings, edges[k], edges[k + 1]) for k in range(nchunk)]
+        if workers > 1 and nchunk > 1:
+            # fresh interpreters (spawn), not forks: the caller may hold an initialised GPU runtime, which a forked copy would
+            # inherit (and count as one more process on the card); the workers only ever import numpy and this module
+            import multiprocessing as mp
+            with mp.get_context("spawn").Pool(workers) as pool:
+                parts = pool.map(_c5_sweep_chunk, jobs)
+        else:
+            parts = [_c5_sweep_chunk(j) for j in jobs]
+        return np.concatenate([p for p, _ in parts]), np.concatenate([q for _, q in parts])
 
     p, nrm = sweep(seed, 0.0)
     p2, n2 = sweep(seed + 1, 0.5)

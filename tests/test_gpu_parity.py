@@ -448,6 +448,67 @@ def test_8m_surface_properties(sym, oracle):
     assert np.abs(r["transform"] - d["truth"]).max() < 2e-4
 
 
+def test_c5_scan_multi_pass_pairs_exact_every_pass(sym, oracle):
+    """C5's density profile (scan rings: the inner ones many times denser than the outer ones, ~100 points per finest Morton cell
+    at full size) through a multi-pass alignment: after EVERY pass the pairs and distances must be the oracle's exact nearest
+    neighbours under that pass's transform -- first pass (packets), the passes after the big move (cell scans + walk) and the
+    certified ones -- and the device-driven run of the same alignment must end on the same transform."""
+    from symmicp import synth
+    d = synth.c5_scan(262144)
+    n = d["src"].shape[0]
+    assert n >= 200000
+    kw = dict(mode=sym.MODE_PAPER, corr=sym.CORR_TREE, max_iters=16, fixed_iters=1)
+    with sym.Engine(host_loop=1, **kw) as e:
+        e.set_target(d["tgt"], d["tgt_n"])
+        e.set_source(d["src"], d["src_n"])
+        e.begin()
+        for k in range(12):
+            idx, d2 = e.correspondences()
+            ri, rd = oracle.nn_grid(d["src"], d["tgt"], X=e.transform())
+            bad = np.flatnonzero(idx != ri)
+            assert bad.size == 0 and np.array_equal(d2, rd), (k, bad[:8])
+            e.step()
+        r_host = e.align()
+    with sym.Engine(**kw) as e:
+        e.set_target(d["tgt"], d["tgt_n"])
+        e.set_source(d["src"], d["src_n"])
+        r_dev = e.align()
+        idx, d2 = e.correspondences()
+        ri, rd = oracle.nn_grid(d["src"], d["tgt"], X=r_dev["transform"])
+        assert np.array_equal(idx, ri) and np.array_equal(d2, rd)
+    assert r_dev["status"] == r_host["status"] == 0 and r_dev["iters"] == r_host["iters"] == 16
+    assert np.abs(r_dev["transform"] - r_host["transform"]).max() < 2e-6
+    assert np.abs(r_dev["transform"] - d["truth"]).max() < 2e-3
+
+
+def test_8m_scan_properties(sym, oracle):
+    """BASELINE's C5 at full size: the 8M-point scan-like pair itself (ray-cast generator, spread over the host's cores).  Size-
+    independent properties: exact nearest neighbours on a sample after the first pass and after 12 iterations (certificates
+    included), the first pass's record against a host recomputation from the returned pairs, convergence to the generating motion."""
+    from symmicp import synth
+    n = 8_000_000
+    d = synth.c5_scan(n, workers=min(16, os.cpu_count() or 1))
+    n = d["src"].shape[0]
+    with sym.Engine(mode=sym.MODE_PAPER, corr=sym.CORR_TREE, max_iters=12, fixed_iters=1) as e:
+        e.set_target(d["tgt"], d["tgt_n"])
+        e.set_source(d["src"], d["src_n"])
+        it0 = e.begin()
+        idx, d2 = e.correspondences()
+        rng = np.random.default_rng(2)
+        sub = rng.choice(n, 20000, replace=False)
+        ri, rd = oracle.nn_grid(d["src"][sub], d["tgt"])
+        assert np.array_equal(idx[sub], ri) and np.array_equal(d2[sub], rd)
+        S = oracle.reduce40(d["src"], d["src_n"], d["tgt"], d["tgt_n"], idx=idx, pivot=e.pivot())
+        _sums_close(it0["sums"], S, 1e-10)
+        assert it0["sums"][34] == n
+        r = e.align()
+        idx, d2 = e.correspondences()
+        ri, rd = oracle.nn_grid(d["src"][sub], d["tgt"], X=r["transform"])
+        assert np.array_equal(idx[sub], ri) and np.array_equal(d2[sub], rd)
+    assert r["status"] == 0 and r["iters"] == 12
+    assert np.abs(r["transform"] - d["truth"]).max() < 2e-3
+
+
 def test_cpp_driver_prints_the_reference_lines(cat, tmp_path):
     """examples/icp_align.cpp (the repo's driver for the C++ MyICP class) run the way the reference's main.cpp runs
     (cat.pcd -> cat_out.pcd, defaults): stdout carries the reference's lines (myicp.cpp:125-126,146-149) and the oracle's
