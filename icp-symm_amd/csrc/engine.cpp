@@ -142,6 +142,7 @@ struct symmicp_ctx {
     float *d2 = nullptr;
     float4 *pairrec = nullptr;       // TREE: per pair, its own copy of the target's (point, normal) record
     float *cert = nullptr;           // TREE pair certificates: one float4 (ref.xyz, clear radius) per source point
+    int32_t *pos2 = nullptr;         // ... and the runner-up of the pairs that hold a two-candidate certificate
     unsigned long long *best64 = nullptr;
     uint32_t *worklist = nullptr, *wl_count = nullptr;   // the sharded work list + its counters
     WorkLists wl{};
@@ -348,7 +349,7 @@ static void free_target(symmicp_ctx *c)
 static void forget_source(symmicp_ctx *c)
 {
     // (the arrays live in one block, c->src_all, which is kept for the next source of the same or a smaller size)
-    c->worklist = c->wl_count = nullptr; c->cert = nullptr; c->pairrec = nullptr;
+    c->worklist = c->wl_count = nullptr; c->cert = nullptr; c->pos2 = nullptr; c->pairrec = nullptr;
     c->src0_block = c->cur_block = nullptr; c->src_order = nullptr; c->pos = nullptr; c->d2 = nullptr; c->best64 = nullptr;
     c->n_loc = c->n_s_total = c->src_off = 0;
 }
@@ -750,6 +751,7 @@ int symmicp_set_source(symmicp_ctx *c, const float *xyz, size_t xr, size_t xc, c
     const size_t o_pos = take(sizeof(int32_t) * nl), o_d2 = take(sizeof(float) * nl);
     const size_t o_best = brute ? take(sizeof(unsigned long long) * nl) : 0;
     const size_t o_cert = tree ? take(sizeof(float) * 4 * nl) : 0;
+    const size_t o_pos2 = tree ? take(sizeof(int32_t) * nl) : 0;
     const size_t o_prec = tree ? take(sizeof(float4) * 2 * nl) : 0;
     const size_t o_wl = tree ? take(sizeof(uint32_t) * 2 * per_list) : 0, o_cnt = tree ? take(sizeof(uint32_t) * 2 * ncount) : 0;      // work + retry lists
     if (off > c->src_all_cap) {
@@ -783,6 +785,7 @@ int symmicp_set_source(symmicp_ctx *c, const float *xyz, size_t xr, size_t xc, c
     }
     if (tree) {
         c->cert = reinterpret_cast<float *>(c->src_all + o_cert);
+        c->pos2 = reinterpret_cast<int32_t *>(c->src_all + o_pos2);
         c->pairrec = reinterpret_cast<float4 *>(c->src_all + o_prec);
         c->worklist = reinterpret_cast<uint32_t *>(c->src_all + o_wl);
         c->wl_count = reinterpret_cast<uint32_t *>(c->src_all + o_cnt);
@@ -876,6 +879,12 @@ static void fill_pass_args(symmicp_ctx *c, PassArgs &a, const float Xapply[16], 
     a.d2_out = (c->cfg.corr == SYMMICP_CORR_IDENTITY) ? nullptr : c->d2;
     a.partials = c->partials;
     a.cert = reinterpret_cast<float4 *>(c->cert);
+    static const bool no_two = std::getenv("SYMMICP_NO_TWO_CANDIDATE") != nullptr;      // A/B runs
+    // two-candidate certificates cost the pairs that get them a second, sequential look at their cells: worth it once the alignment
+    // is settling (the previous pass searched under 1 in 8 pairs), not while every certificate is about to be invalidated anyway
+    // (passes 2-3 of a 30-iteration alignment: +50 / +16 us with them); existing ones are honoured either way
+    a.pos2 = no_two ? nullptr : c->pos2;
+    a.make_two_candidate = (!first && c->last_uncertified >= 0 && c->last_uncertified < (long long)(c->n_s_total / 8)) ? 1 : 0;
     a.pairrec = c->pairrec;
     // sharded runs: the first pass over a small share is bound by its slowest walks, not by throughput
     static const char *bw_env = std::getenv("SYMMICP_BUDGET_WALK");        // "0" never, "1" always (tests), unset: auto
@@ -1093,6 +1102,7 @@ static int run_batch(symmicp_ctx *c, int want, float *diffs_before, int *n_done,
     PassArgs a{};
     fill_pass_args(c, a, c->X, /*from_cur=*/incr, /*writeback=*/incr, /*first=*/false);
     a.loop = c->d_loop;
+    a.make_two_candidate = 1;
     int blocks;
     bool vec4 = false;
     if (tree) {
@@ -1396,6 +1406,19 @@ int symmicp_get_source(symmicp_ctx *c, float *xyz, float *nrm, size_t cap)
     launch_unpermute(c->cur, c->src_order, c->n_loc, dx.p, dn.p, c->stream);
     if (xyz) HIP_TRY(c, hipMemcpyAsync(xyz, dx.p, sizeof(float) * 3 * need, hipMemcpyDeviceToHost, c->stream));
     if (nrm) HIP_TRY(c, hipMemcpyAsync(nrm, dn.p, sizeof(float) * 3 * need, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return SYMMICP_OK;
+}
+
+// diagnostic: the pair certificates as they stand, in the share's sorted order (ref.xyz, L; L = 0 none, L < 0 two candidates: -L3)
+int symmicp_get_certificates(symmicp_ctx *c, float *cert4, int32_t *runner_up, size_t cap)
+{
+    if (!c || !cert4) return SYMMICP_ERR_ARG;
+    if (!c->begun || !c->cert) return fail(c, SYMMICP_ERR_STATE, "no tree pass has run yet");
+    if (cap < c->n_loc) return fail(c, SYMMICP_ERR_SIZE, "output too small");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipMemcpyAsync(cert4, c->cert, sizeof(float) * 4 * c->n_loc, hipMemcpyDeviceToHost, c->stream));
+    if (runner_up) HIP_TRY(c, hipMemcpyAsync(runner_up, c->pos2, sizeof(int32_t) * c->n_loc, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return SYMMICP_OK;
 }

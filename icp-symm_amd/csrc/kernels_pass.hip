@@ -308,7 +308,31 @@ __device__ __forceinline__ float axis_gap2(float p, float origin, int c, float h
 // grid's own absolute margin and keep 1e-5.  Pairs whose two nearest points are closer together than that - a few
 // dozen per million - have no certificate and are searched again in every pass.
 // ---------------------------------------------------------------------------
-constexpr float kSlackFrac = 0.25f;
+// Two-candidate certificates.  A pair whose two nearest target points are (nearly) equally far has L <= d1 and could never be
+// certified, and one whose slack L - d1 is below the last-bit jitter of a converged transform fails its certificate in every pass:
+// ~70-90 such pairs per million send their blocks through the scan machinery in every converged pass (8 of the 29 us of k_pass_fused).  For them the scan also notes the runner-up b and the distance of the THIRD-nearest point: with
+// L3 = min(third scanned, lim) every point other than a and b is >= L3 from p_ref, so while max(d_a', d_b') + delta < L3 the
+// nearest neighbour is a or b, decided by the same fp32 (d2, row) comparison brute force makes -- two 16-byte gathers instead of a
+// scan.  Stored as cert.w = -L3 (negative: two candidates) and pos2[i] = b; the pair's record copy holds the current winner.
+constexpr float kSlackFrac = 0.25f;      // (0.125 / 0.5 / 1.0 measured on the 1M surface pair and the 2M scan pair: within noise or worse)
+
+// Certificate test for a two-candidate pair (cert.w = -L3).  In: the query's position, its distance to the current winner a
+// (d2a, rowa), the certificate.  True: the nearest neighbour is provably a or b; `swap` tells that b now wins (the caller makes b
+// the pair: position, record copy, pos2 <- a) and d2w / roww are the winner's.
+__device__ __forceinline__ bool two_candidate_test(const PassArgs &a, const TargetIndex &ix, uint32_t i, float px, float py, float pz, float d2a, int32_t rowa,
+                                                   const float4 &ce, int32_t &p2, float4 &qb, bool &swap)
+{
+    swap = false;
+    p2 = a.pos2[i];
+    if (p2 < 0 || (uint32_t)p2 >= ix.n) return false;
+    qb = ix.tq[p2];
+    const float d2b = dist2(px, py, pz, qb.x, qb.y, qb.z);
+    const float m2 = dist2(px, py, pz, ce.x, ce.y, ce.z);
+    if (!((__builtin_amdgcn_sqrtf(fmaxf(d2a, d2b)) + __builtin_amdgcn_sqrtf(m2)) * 1.000002f < -ce.w)) return false;
+    const int32_t rowb = __float_as_int(qb.w);
+    swap = (d2b < d2a) || (d2b == d2a && rowb < rowa);
+    return true;
+}
 
 // One tile of 256 queries (i >= a.n: idle lane).  Called by k_search_cells (tile = block) and by k_pass_fused (the queries its
 // streaming phase could not certify).
@@ -351,9 +375,19 @@ __device__ __forceinline__ void cells_tile(const PassArgs &a, const TargetIndex 
             if (d2 <= inf) { b.d2 = d2; b.pos = prev; b.row = row; }                      // (not NaN)
         }
         bool certified = false;
-        if (a.use_slack && b.pos >= 0) {
+        if (a.use_slack && b.pos >= 0 && clear >= 0.0f) {
             const float m2 = dist2(px, py, pz, rx, ry, rz);                               // delta^2
             certified = (__builtin_amdgcn_sqrtf(b.d2) + __builtin_amdgcn_sqrtf(m2)) * 1.000002f < clear;     // 1-ulp roots, inside the margin
+        } else if (a.use_slack && b.pos >= 0) {
+            // two-candidate pair: the winner is the previous winner or its runner-up
+            int32_t p2; float4 qb; bool swap;
+            certified = two_candidate_test(a, ix, i, px, py, pz, b.d2, b.row, make_float4(rx, ry, rz, clear), p2, qb, swap);
+            if (certified && swap) {
+                a.pos2[i] = b.pos;
+                b.d2 = dist2(px, py, pz, qb.x, qb.y, qb.z); b.pos = p2; b.row = __float_as_int(qb.w);
+                a.pos_out[i] = p2;
+                store_pair_record(a, ix, i, p2);
+            }
         }
         if (certified) {
             a.d2_out[i] = b.d2;          // same pair, refreshed distance; position, certificate unchanged
@@ -466,6 +500,7 @@ __device__ __forceinline__ void cells_tile(const PassArgs &a, const TargetIndex 
     s_pos[tid] = b.pos;
     s_key[tid] = (b.pos >= 0) ? (((unsigned long long)__float_as_uint(b.d2) << 32) | (unsigned long long)(uint32_t)b.row) : ~0ull;
     s_second[tid] = 0x7f800000u;
+    uint32_t mask_scanned = mask;      // every cell this query has scanned by the end (two-candidate certificates rescan them)
     uint32_t total = 0, total_all = 0;
     for (int round = 0; round < 2; round++) {
     // block-wide exclusive prefix sum of the item counts
@@ -567,6 +602,7 @@ __device__ __forceinline__ void cells_tile(const PassArgs &a, const TargetIndex 
         if (!(d1 < lim)) { more = (mask_rest != 0); lim = lim_full; }
     }
     mask = more ? mask_rest : 0u;
+    mask_scanned |= mask;
     if (round == 1) break;
     {
         const unsigned long long anym = __ballot(more);
@@ -604,7 +640,38 @@ __device__ __forceinline__ void cells_tile(const PassArgs &a, const TargetIndex 
             // certificate for the following passes
             const float second = sqrtf(__uint_as_float(s_second[tid])) * 0.999999f;
             const float L = fminf(second, lim * 0.99999f);
-            a.cert[i] = make_float4(px, py, pz, (L > d1) ? L : 0.0f);
+            float Lw = (L > d1) ? L : 0.0f;
+            if (!(L > d1 * 1.001f) && a.use_slack && a.pos2 && a.make_two_candidate) {
+                // (almost) no room between the two nearest points -- under 0.1 % of d1: at convergence the transform still jitters in
+                // its last bits, and a pair whose slack is below that jitter (~70 per million with slack < 5e-5 d1) would fail its
+                // certificate in every pass.  Scan this query's cells once more, alone, for the runner-up and the third-nearest
+                // distance (~2000 queries per million, in the passes that search them anyway)
+                unsigned long long k1 = ~0ull, k2 = ~0ull;      // (d2 bits << 32 | row) of the nearest and the runner-up
+                int32_t p1 = -1, p2 = -1;                       // ... and their sorted positions
+                uint32_t d3 = 0x7f800000u;                      // d2 bits of the third-nearest
+                const uint32_t c0 = s_cell0[tid];
+                for (uint32_t m = mask_scanned; m; m &= m - 1) {
+                    const int bit = __ffs((int)m) - 1;
+                    const int kz = bit / 9, ky = (bit - 9 * kz) / 3, kx = bit - 9 * kz - 3 * ky;
+                    const uint32_t cx = (c0 & 1023u) + (uint32_t)kx, cy = ((c0 >> 10) & 1023u) + (uint32_t)ky, cz = (c0 >> 20) + (uint32_t)kz;
+                    const uint2 rng = cell_range(ix, (spread3(cz) << 2) | (spread3(cy) << 1) | spread3(cx));
+                    for (uint32_t j = rng.x; j < rng.y; j++) {
+                        const float4 t = ix.tq[j];
+                        const float d2 = dist2(px, py, pz, t.x, t.y, t.z);
+                        if (!(d2 == d2)) continue;
+                        const unsigned long long kk = ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned long long)(uint32_t)__float_as_int(t.w);
+                        if (kk < k1) { d3 = min(d3, (uint32_t)(k2 >> 32)); k2 = k1; p2 = p1; k1 = kk; p1 = (int32_t)j; }
+                        else if (kk < k2) { d3 = min(d3, (uint32_t)(k2 >> 32)); k2 = kk; p2 = (int32_t)j; }
+                        else d3 = min(d3, __float_as_uint(d2));
+                    }
+                }
+                if (k1 == key && p1 == s_pos[tid] && p2 >= 0) {
+                    const float db = sqrtf(__uint_as_float((uint32_t)(k2 >> 32))) * 1.000001f;
+                    const float L3 = fminf(sqrtf(__uint_as_float(d3)) * 0.999999f, lim * 0.99999f);
+                    if (L3 > db) { Lw = -L3; a.pos2[i] = p2; }
+                }
+            }
+            a.cert[i] = make_float4(px, py, pz, Lw);
             store_pair_record(a, ix, i, s_pos[tid]);
         }
     }
@@ -620,8 +687,8 @@ __global__ __launch_bounds__(kPassThreads) void k_search_cells(PassArgs a, Targe
 // certified, so the pass is a stream: per point 12 B position + 12 B normal + the pair's own 32-byte record copy + the
 // 16-byte certificate, all coalesced; certified pairs are accumulated on the spot (rows of func.cpp:51-58, 37 fp64 sums).
 // Separate search and accumulate kernels read the source twice and cost two launches.
-//   stream   grid-stride over tiles of 256 points: certificate test (the expressions of cells_tile, phase 1); a pair that
-//            fails it goes to a list in LDS
+//   stream   grid-stride over tiles of 256 points: certificate test (the expressions of cells_tile, phase 1; two candidates where
+//            the pair carries them); a pair that fails goes to a list in LDS
 //   scan     the listed queries run through cells_tile, 256 at a time: exact scan, new pair, certificate and record copy
 //   settle   the listed queries once more: those that now have a pair are accumulated from their fresh record copy
 // A query the scan has to hand to the tree walk is appended to the work list and NOT accumulated (its record copy is
@@ -667,14 +734,28 @@ __global__ __launch_bounds__(kPassThreads, FUSED_WAVES) void k_pass_fused(PassAr
         const float px = xf_row(X.m + 0, x, y, z, 1.0f), py = xf_row(X.m + 4, x, y, z, 1.0f), pz = xf_row(X.m + 8, x, y, z, 1.0f);
         bool certified = false;
         float d2 = 0.0f;
+        float4 qw = q, nqw = nq;                               // the pair that is accumulated
         if (nq.w == 0.0f) {                                    // a fresh copy of the previous winner (same bits as tq[prev])
             d2 = dist2(px, py, pz, q.x, q.y, q.z);
-            const float m2 = dist2(px, py, pz, ce.x, ce.y, ce.z);
-            certified = (__builtin_amdgcn_sqrtf(d2) + __builtin_amdgcn_sqrtf(m2)) * 1.000002f < ce.w;          // cells_tile, phase 1
+            if (ce.w >= 0.0f) {
+                const float m2 = dist2(px, py, pz, ce.x, ce.y, ce.z);
+                certified = (__builtin_amdgcn_sqrtf(d2) + __builtin_amdgcn_sqrtf(m2)) * 1.000002f < ce.w;      // cells_tile, phase 1
+            } else {
+                // two-candidate pair (see kSlackFrac): the winner is the previous winner or its runner-up
+                int32_t p2; float4 qb; bool swap;
+                certified = two_candidate_test(a, ix, i, px, py, pz, d2, __float_as_int(q.w), ce, p2, qb, swap);
+                if (certified && swap) {
+                    a.pos2[i] = a.pos_prev[i];
+                    a.pos_out[i] = p2;
+                    qw = ix.tn[2 * (size_t)p2]; nqw = ix.tn[2 * (size_t)p2 + 1];
+                    a.pairrec[2 * (size_t)i] = qw; a.pairrec[2 * (size_t)i + 1] = nqw;
+                    d2 = dist2(px, py, pz, qw.x, qw.y, qw.z);
+                }
+            }
         }
         if (certified) {
-            a.d2_out[i] = d2;                                  // same pair, refreshed distance
-            fused_accumulate(acc, a, X, nx, ny, nz, px, py, pz, q, nq, d2);
+            a.d2_out[i] = d2;                                  // refreshed distance of the (possibly swapped) pair
+            fused_accumulate(acc, a, X, nx, ny, nz, px, py, pz, qw, nqw, d2);
         } else {
             const uint32_t k = atomicAdd(&s_cnt, 1u);
             if (k < (uint32_t)kFusedList) s_list[k] = i;

@@ -135,7 +135,9 @@ struct PassArgs {
     float4 *pairrec;                    // TREE: per pair, its own copy of the target's (point, normal) record (2 float4)
     int32_t budget_walk;                // this pass's thread-per-query walk runs with a visit budget + retry launch (see k_search_walk)
     int32_t refresh_records;            // k_accumulate may replace stale copies (0 in a pass that may still be repaired)
-    float4 *cert;                       // per pair: (ref.xyz, clear radius L around ref; L = 0: no certificate)
+    float4 *cert;                       // per pair: (ref.xyz, clear radius L around ref; L = 0: no certificate; L < 0: two-candidate certificate, -L3)
+    int32_t *pos2;                      // per pair with a two-candidate certificate: sorted position of the runner-up
+    int32_t make_two_candidate;         // this pass may create two-candidate certificates (it always honours existing ones)
     int32_t use_slack;                  // 0 on the first pass of an alignment (certificates not valid yet)
     const LoopState *loop;              // device-driven loop: the transform comes from here (null: from X above)
 };

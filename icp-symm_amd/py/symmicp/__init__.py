@@ -71,7 +71,7 @@ EXPORTS = [
     "symmicp_config_default", "symmicp_create", "symmicp_destroy", "symmicp_last_error", "symmicp_set_config",
     "symmicp_version", "symmicp_set_source", "symmicp_set_target", "symmicp_align", "symmicp_begin", "symmicp_step",
     "symmicp_get_transform", "symmicp_get_pivot", "symmicp_get_correspondences", "symmicp_get_source",
-    "symmicp_local_source_count", "symmicp_local_source_offset", "symmicp_solve", "symmicp_comm_get_unique_id",
+    "symmicp_local_source_count", "symmicp_local_source_offset", "symmicp_get_certificates", "symmicp_solve", "symmicp_comm_get_unique_id",
     "symmicp_comm_init_rank", "symmicp_set_sums", "symmicp_comm_init_shm", "symmicp_shard_range", "symmicp_get_stats", "symmicp_reset_stats", "symmicp_enable_timing",
     "symmicp_pcd_read", "symmicp_pcd_write", "symmicp_estimate_normals", "symmicp_ctx_estimate_normals",
 ]
@@ -344,6 +344,14 @@ class Engine:
                     transform=np.array(res.transform, np.float32).reshape(4, 4),
                     diffs=np.array(res.diffs[:n], np.float32), seconds=res.seconds_total,
                     error=(self._L.symmicp_last_error(self._h) or b"").decode() if st != OK else "")
+
+    def certificates(self):
+        """diagnostic: (cert [n_loc, 4], runner_up [n_loc]) of this rank's share, in its sorted order"""
+        n = self.local_count()
+        ce = np.zeros((n, 4), np.float32)
+        ru = np.zeros(n, np.int32)
+        self._chk(self._L.symmicp_get_certificates(self._h, _fptr(ce), ru.ctypes.data_as(C.POINTER(C.c_int32)), C.c_size_t(n)))
+        return ce, ru
 
     def transform(self):
         X = np.zeros(16, np.float32)

@@ -158,6 +158,10 @@ int symmicp_get_pivot(const symmicp_ctx *ctx, float out3[3]);
 int symmicp_get_correspondences(symmicp_ctx *ctx, int32_t *idx, float *d2, size_t cap);
 /* current (transformed) source points / normals of this rank's share, original row order, packed AoS. */
 int symmicp_get_source(symmicp_ctx *ctx, float *xyz, float *nrm, size_t cap);
+/* diagnostic (SYMMICP_CORR_TREE): the pair certificates of this rank's share in its sorted order: cert4 [n_loc][4] = position of the
+ * query when its pair was last searched + the clear radius L (0: none; < 0: two-candidate certificate, -L3); runner_up (may be
+ * NULL) [n_loc]: sorted target position of the second candidate where L < 0 */
+int symmicp_get_certificates(symmicp_ctx *ctx, float *cert4, int32_t *runner_up, size_t cap);
 size_t symmicp_local_source_count(const symmicp_ctx *ctx);
 size_t symmicp_local_source_offset(const symmicp_ctx *ctx);
 
