@@ -151,6 +151,59 @@ def _c5_sweep_chunk(args):
     return origin + d * (s + noise)[:, None], _scan_normals(clean)
 
 
+def _c5_worker_main():
+    """child side of _c5_run_jobs: jobs (pickled by the parent) on stdin, one .npy pair per job on stdout"""
+    import io
+    import pickle
+    import sys
+    out = sys.stdout.buffer
+    for job in pickle.load(sys.stdin.buffer):
+        for arr in _c5_sweep_chunk(job):
+            buf = io.BytesIO()                      # np.save wants a seekable file; stdout is a pipe
+            np.save(buf, arr)
+            out.write(buf.getbuffer())
+    out.flush()
+
+
+def _c5_run_jobs(jobs, workers):
+    """The chunks on `workers` child interpreters.  Children are started as `python -c` (not fork: the caller may hold an
+    initialised GPU runtime, which a forked copy would inherit and which would count as one more process on the card; not a
+    multiprocessing pool: a spawned pool re-runs the caller's main module, which hangs scripts without a __main__ guard);
+    they import numpy and this file only."""
+    import io
+    import os
+    import pickle
+    import subprocess
+    import sys
+    import threading
+    # this file alone, by path: the package's __init__ (which binds the HIP library) stays out of the children
+    code = ("import importlib.util as u; s = u.spec_from_file_location('symmicp_synth', %r); m = u.module_from_spec(s); "
+            "s.loader.exec_module(m); m._c5_worker_main()") % os.path.abspath(__file__)
+    workers = min(workers, len(jobs))
+    shares = [list(range(w, len(jobs), workers)) for w in range(workers)]
+    outs, errs = [None] * workers, [None] * workers
+
+    def drive(w):
+        pr = subprocess.Popen([sys.executable, "-c", code], stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        outs[w], errs[w] = pr.communicate(pickle.dumps([jobs[k] for k in shares[w]]))
+        if pr.returncode != 0:
+            outs[w] = None
+
+    threads = [threading.Thread(target=drive, args=(w,)) for w in range(workers)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    parts = [None] * len(jobs)
+    for w in range(workers):
+        if outs[w] is None:
+            raise RuntimeError("c5_scan worker failed: " + (errs[w] or b"").decode(errors="replace")[-400:])
+        buf = io.BytesIO(outs[w])
+        for k in shares[w]:
+            parts[k] = (np.load(buf), np.load(buf))
+    return parts
+
+
 def c5_scan(n=8_000_000, seed=0xC5, rings=64, workers=None):
     """C5, scan-like: a sensor 1.2 above the (periodically extended) C4 height field sweeps `rings`
     cones (5..40 deg off nadir) x n/rings azimuth samples; rays are cast onto the surface, which is
@@ -169,14 +222,7 @@ def c5_scan(n=8_000_000, seed=0xC5, rings=64, workers=None):
 
     def sweep(sd, phase):
         jobs = [(sd, phase, per, rings, edges[k], edges[k + 1]) for k in range(nchunk)]
-        if workers > 1 and nchunk > 1:
-            # fresh interpreters (spawn), not forks: the caller may hold an initialised GPU runtime, which a forked copy would
-            # inherit (and count as one more process on the card); the workers only ever import numpy and this module
-            import multiprocessing as mp
-            with mp.get_context("spawn").Pool(workers) as pool:
-                parts = pool.map(_c5_sweep_chunk, jobs)
-        else:
-            parts = [_c5_sweep_chunk(j) for j in jobs]
+        parts = _c5_run_jobs(jobs, workers) if workers > 1 and nchunk > 1 else [_c5_sweep_chunk(j) for j in jobs]
         return np.concatenate([p for p, _ in parts]), np.concatenate([q for _, q in parts])
 
     p, nrm = sweep(seed, 0.0)
