@@ -142,7 +142,8 @@ struct symmicp_ctx {
     float *d2 = nullptr;
     float4 *pairrec = nullptr;       // TREE: per pair, its own copy of the target's (point, normal) record
     float *cert = nullptr;           // TREE pair certificates: one float4 (ref.xyz, clear radius) per source point
-    int32_t *pos2 = nullptr;         // ... and the runner-up of the pairs that hold a two-candidate certificate
+    uint32_t *certk = nullptr;       // ... and their neighbourhood certificates: 8 member words per source point
+    float *hoodr = nullptr;          // ... (T, radius hint) per source point
     unsigned long long *best64 = nullptr;
     uint32_t *worklist = nullptr, *wl_count = nullptr;   // the sharded work list + its counters
     WorkLists wl{};
@@ -349,7 +350,7 @@ static void free_target(symmicp_ctx *c)
 static void forget_source(symmicp_ctx *c)
 {
     // (the arrays live in one block, c->src_all, which is kept for the next source of the same or a smaller size)
-    c->worklist = c->wl_count = nullptr; c->cert = nullptr; c->pos2 = nullptr; c->pairrec = nullptr;
+    c->worklist = c->wl_count = nullptr; c->cert = nullptr; c->certk = nullptr; c->hoodr = nullptr; c->pairrec = nullptr;
     c->src0_block = c->cur_block = nullptr; c->src_order = nullptr; c->pos = nullptr; c->d2 = nullptr; c->best64 = nullptr;
     c->n_loc = c->n_s_total = c->src_off = 0;
 }
@@ -701,8 +702,8 @@ int symmicp_set_target(symmicp_ctx *c, const float *xyz, size_t xr, size_t xc, c
                      &c->onodes, &c->ctop);
     if (st != SYMMICP_OK) { free_target(c); return st; }
     if (std::getenv("SYMMICP_DEBUG_COUNTERS")) {
-        HIP_TRY(c, hipMalloc((void **)&c->dbg, 8 * sizeof(unsigned long long)));
-        HIP_TRY(c, hipMemset(c->dbg, 0, 8 * sizeof(unsigned long long)));
+        HIP_TRY(c, hipMalloc((void **)&c->dbg, 12 * sizeof(unsigned long long)));
+        HIP_TRY(c, hipMemset(c->dbg, 0, 12 * sizeof(unsigned long long)));
         c->ix.dbg = c->dbg;
         if (std::getenv("SYMMICP_DEBUG_TRACE")) {
             HIP_TRY(c, hipMalloc((void **)&c->dbg_trace, ((size_t)1 << 21) * 16));
@@ -751,7 +752,7 @@ int symmicp_set_source(symmicp_ctx *c, const float *xyz, size_t xr, size_t xc, c
     const size_t o_pos = take(sizeof(int32_t) * nl), o_d2 = take(sizeof(float) * nl);
     const size_t o_best = brute ? take(sizeof(unsigned long long) * nl) : 0;
     const size_t o_cert = tree ? take(sizeof(float) * 4 * nl) : 0;
-    const size_t o_pos2 = tree ? take(sizeof(int32_t) * nl) : 0;
+    const size_t o_certk = tree ? take(sizeof(uint32_t) * 8 * nl) : 0, o_hoodr = tree ? take(sizeof(float) * 2 * nl) : 0;
     const size_t o_prec = tree ? take(sizeof(float4) * 2 * nl) : 0;
     const size_t o_wl = tree ? take(sizeof(uint32_t) * 2 * per_list) : 0, o_cnt = tree ? take(sizeof(uint32_t) * 2 * ncount) : 0;      // work + retry lists
     if (off > c->src_all_cap) {
@@ -785,7 +786,9 @@ int symmicp_set_source(symmicp_ctx *c, const float *xyz, size_t xr, size_t xc, c
     }
     if (tree) {
         c->cert = reinterpret_cast<float *>(c->src_all + o_cert);
-        c->pos2 = reinterpret_cast<int32_t *>(c->src_all + o_pos2);
+        c->certk = reinterpret_cast<uint32_t *>(c->src_all + o_certk);      // (validity lives in bit 0 of the certificate word: no clearing needed)
+        c->hoodr = reinterpret_cast<float *>(c->src_all + o_hoodr);
+        HIP_TRY(c, hipMemsetAsync(c->hoodr, 0, sizeof(float) * 2 * nl, c->stream));                // no radius hints yet
         c->pairrec = reinterpret_cast<float4 *>(c->src_all + o_prec);
         c->worklist = reinterpret_cast<uint32_t *>(c->src_all + o_wl);
         c->wl_count = reinterpret_cast<uint32_t *>(c->src_all + o_cnt);
@@ -879,12 +882,11 @@ static void fill_pass_args(symmicp_ctx *c, PassArgs &a, const float Xapply[16], 
     a.d2_out = (c->cfg.corr == SYMMICP_CORR_IDENTITY) ? nullptr : c->d2;
     a.partials = c->partials;
     a.cert = reinterpret_cast<float4 *>(c->cert);
-    static const bool no_two = std::getenv("SYMMICP_NO_TWO_CANDIDATE") != nullptr;      // A/B runs
-    // two-candidate certificates cost the pairs that get them a second, sequential look at their cells: worth it once the alignment
-    // is settling (the previous pass searched under 1 in 8 pairs), not while every certificate is about to be invalidated anyway
-    // (passes 2-3 of a 30-iteration alignment: +50 / +16 us with them); existing ones are honoured either way
-    a.pos2 = no_two ? nullptr : c->pos2;
-    a.make_two_candidate = (!first && c->last_uncertified >= 0 && c->last_uncertified < (long long)(c->n_s_total / 8)) ? 1 : 0;
+    static const bool no_hood = std::getenv("SYMMICP_NO_NEIGHBOURHOOD") != nullptr;      // A/B runs
+    a.certk = no_hood ? nullptr : reinterpret_cast<uint4 *>(c->certk);
+    a.hoodr = reinterpret_cast<float2 *>(c->hoodr);
+    // neighbourhoods are worth their stores once the alignment is settling (the previous pass searched under half of the pairs)
+    a.make_hood = (a.certk && !first && c->last_uncertified >= 0 && c->last_uncertified < (long long)(c->n_s_total / 2)) ? 1 : 0;
     a.pairrec = c->pairrec;
     // sharded runs: the first pass over a small share is bound by its slowest walks, not by throughput
     static const char *bw_env = std::getenv("SYMMICP_BUDGET_WALK");        // "0" never, "1" always (tests), unset: auto
@@ -960,7 +962,14 @@ static int run_pass(symmicp_ctx *c, const float Xapply[16], bool from_cur, bool 
             // per-kernel events only in timing mode 2; mode 1 brackets the pass (events 0 and 4)
             if (first && c->target_surface_like) launch_pass_tree_first(a, c->ix, c->wl, ab, c->stream, c->timing == 2 ? ev : nullptr);
             else
-            launch_pass_tree_split(a, c->ix, c->wl, ab, walk_blocks, optimistic ? 1 : 0, c->stream, c->timing == 2 ? ev : nullptr);
+            {
+                // Sparse scans (the previous pass searched under a tenth of the pairs): the streaming kernel compacts the
+                // failures of several tiles into full scan rounds; blocks enough to fill the chip at 5 waves per SIMD
+                static const char *cp_env = std::getenv("SYMMICP_COMPACT");        // "0" never, "1" always (tests), unset: auto
+                static const int cp_blocks = std::getenv("SYMMICP_COMPACT_BLOCKS") ? std::atoi(std::getenv("SYMMICP_COMPACT_BLOCKS")) : 1280;
+                const bool compact = a.use_slack && (cp_env ? (cp_env[0] == '1') : (c->last_uncertified >= 0 && c->last_uncertified < (long long)(c->n_s_total / 10)));
+                launch_pass_tree_split(a, c->ix, c->wl, ab, walk_blocks, optimistic ? 1 : 0, compact ? cp_blocks : 0, c->stream, c->timing == 2 ? ev : nullptr);
+            }
             if (ev && c->timing == 2) c->ev_split[c->ev_used] = 2;
         }
         break;
@@ -1011,7 +1020,7 @@ static int run_pass(symmicp_ctx *c, const float Xapply[16], bool from_cur, bool 
     if (optimistic && list_len > 0) {
         // the walk was skipped but some queries needed it: their pairs are provisional, so are the sums
         c->st.kernel_launches[7]++;
-        launch_pass_tree_split(a, c->ix, c->wl, blocks, list_len <= 50000 ? 8192u : 0u, 2, c->stream, nullptr);
+        launch_pass_tree_split(a, c->ix, c->wl, blocks, list_len <= 50000 ? 8192u : 0u, 2, 0, c->stream, nullptr);
         if (ev && c->ev_split[c->ev_used] != 2) hipEventRecord(ev[4], c->stream);
         if (int st = reduce_and_wait(0)) return st;
         if (c->shm.slots) { if (int st = shm_exchange(c, c->h_sums)) return st; }
@@ -1019,7 +1028,7 @@ static int run_pass(symmicp_ctx *c, const float Xapply[16], bool from_cur, bool 
     if (ev) c->ev_used++;
     c->t_last_done = now_s(); c->n_pass_timed++;
     if (c->ix.dbg) {
-        unsigned long long h[8];
+        unsigned long long h[12];
         hipMemcpy(h, c->ix.dbg, sizeof(h), hipMemcpyDeviceToHost);
         hipMemset(c->ix.dbg, 0, sizeof(h));
         if (c->dbg_trace && first) {
@@ -1035,8 +1044,8 @@ static int run_pass(symmicp_ctx *c, const float Xapply[16], bool from_cur, bool 
             std::fprintf(stderr, "[symmicp dbg] pass %lld (packets): steps=%llu nodes+leaf candidates=%llu leaf candidates rejected=%llu points=%llu tie rescans=%llu overflows=%llu | packet ticks (10 ns): sum=%llu max=%llu\n",
                          (long long)c->st.passes, h[0], h[4], h[5], h[3], h[2], h[1], h[7], h[6]);
         else
-        std::fprintf(stderr, "[symmicp dbg] pass %lld: cells: certified=%llu scans=%llu probes=%llu to-walk=%llu items=%llu points=%llu | walk list=%lld visits=%llu wave-max*64=%llu\n",
-                     (long long)c->st.passes, h[1], h[2], h[6], h[7], h[0], h[3], list_len, h[4], h[5]);
+        std::fprintf(stderr, "[symmicp dbg] pass %lld: cells: certified=%llu (by neighbourhood %llu) scans=%llu (neighbourhoods kept %llu, not kept %llu) probes=%llu to-walk=%llu items=%llu points=%llu | walk list=%lld visits=%llu wave-max*64=%llu\n",
+                     (long long)c->st.passes, h[1], h[8], h[2], h[9], h[10], h[6], h[7], h[0], h[3], list_len, h[4], h[5]);
     }
     std::memcpy(c->last.s, c->h_sums, sizeof(double) * kNSum);
     if (c->cfg.corr == SYMMICP_CORR_TREE) c->last.s[kNSum - 1] = c->last.s[kNSum - 2] = c->last.s[kNSum - 3] = 0.0;      // those slots carried the list length and the number of searched pairs, not sums
@@ -1102,7 +1111,6 @@ static int run_batch(symmicp_ctx *c, int want, float *diffs_before, int *n_done,
     PassArgs a{};
     fill_pass_args(c, a, c->X, /*from_cur=*/incr, /*writeback=*/incr, /*first=*/false);
     a.loop = c->d_loop;
-    a.make_two_candidate = 1;
     int blocks;
     bool vec4 = false;
     if (tree) {
@@ -1410,16 +1418,32 @@ int symmicp_get_source(symmicp_ctx *c, float *xyz, float *nrm, size_t cap)
     return SYMMICP_OK;
 }
 
-// diagnostic: the pair certificates as they stand, in the share's sorted order (ref.xyz, L; L = 0 none, L < 0 two candidates: -L3)
-int symmicp_get_certificates(symmicp_ctx *c, float *cert4, int32_t *runner_up, size_t cap)
+// diagnostic: the pair certificates as they stand, in the share's sorted order: (ref.xyz, L), the neighbourhood's 8 members and radius, the
+// current winner, target points named by their ROW in the caller's target cloud (the device holds sorted positions)
+int symmicp_get_certificates(symmicp_ctx *c, float *cert4, uint32_t *hood8, float *hood_radius, int32_t *winner_row, size_t cap)
 {
     if (!c || !cert4) return SYMMICP_ERR_ARG;
     if (!c->begun || !c->cert) return fail(c, SYMMICP_ERR_STATE, "no tree pass has run yet");
     if (cap < c->n_loc) return fail(c, SYMMICP_ERR_SIZE, "output too small");
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipMemcpyAsync(cert4, c->cert, sizeof(float) * 4 * c->n_loc, hipMemcpyDeviceToHost, c->stream));
-    if (runner_up) HIP_TRY(c, hipMemcpyAsync(runner_up, c->pos2, sizeof(int32_t) * c->n_loc, hipMemcpyDeviceToHost, c->stream));
+    std::vector<int32_t> pos(winner_row ? c->n_loc : 0);
+    std::vector<float> tq((hood8 || winner_row) ? (size_t)c->n_t * 4 : 0);
+    if (hood8) HIP_TRY(c, hipMemcpyAsync(hood8, c->certk, sizeof(uint32_t) * 8 * c->n_loc, hipMemcpyDeviceToHost, c->stream));
+    std::vector<float> tr(hood_radius ? (size_t)c->n_loc * 2 : 0);
+    if (hood_radius) HIP_TRY(c, hipMemcpyAsync(tr.data(), c->hoodr, sizeof(float) * 2 * c->n_loc, hipMemcpyDeviceToHost, c->stream));
+    if (winner_row) HIP_TRY(c, hipMemcpyAsync(pos.data(), c->pos, sizeof(int32_t) * c->n_loc, hipMemcpyDeviceToHost, c->stream));
+    if (!tq.empty()) HIP_TRY(c, hipMemcpyAsync(tq.data(), c->tq, sizeof(float) * 4 * c->n_t, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    auto row_of = [&](uint32_t p) -> uint32_t {
+        if (p >= c->n_t) return 0xFFFFFFFFu;
+        uint32_t r; std::memcpy(&r, &tq[(size_t)p * 4 + 3], 4); return r;      // the row rides in the w slot of the sorted point
+    };
+    for (size_t i = 0; i < c->n_loc; i++) {
+        if (hood8) for (int k = 0; k < 8; k++) hood8[i * 8 + k] = row_of(hood8[i * 8 + k]);
+        if (winner_row) winner_row[i] = pos[i] < 0 ? -1 : (int32_t)row_of((uint32_t)pos[i]);
+        if (hood_radius) hood_radius[i] = tr[i * 2];
+    }
     return SYMMICP_OK;
 }
 

@@ -308,36 +308,85 @@ __device__ __forceinline__ float axis_gap2(float p, float origin, int c, float h
 // grid's own absolute margin and keep 1e-5.  Pairs whose two nearest points are closer together than that - a few
 // dozen per million - have no certificate and are searched again in every pass.
 // ---------------------------------------------------------------------------
-// Two-candidate certificates.  A pair whose two nearest target points are (nearly) equally far has L <= d1 and could never be
-// certified, and one whose slack L - d1 is below the last-bit jitter of a converged transform fails its certificate in every pass:
-// ~70-90 such pairs per million send their blocks through the scan machinery in every converged pass (8 of the 29 us of k_pass_fused).  For them the scan also notes the runner-up b and the distance of the THIRD-nearest point: with
-// L3 = min(third scanned, lim) every point other than a and b is >= L3 from p_ref, so while max(d_a', d_b') + delta < L3 the
-// nearest neighbour is a or b, decided by the same fp32 (d2, row) comparison brute force makes -- two 16-byte gathers instead of a
-// scan.  Stored as cert.w = -L3 (negative: two candidates) and pos2[i] = b; the pair's record copy holds the current winner.
+// Neighbourhood certificates.  The single certificate above has only the room between the two nearest points, L - d1; while an
+// alignment still drifts (the scan-like pair keeps moving by a fraction of its point spacing for a dozen passes) that room is used
+// up within a pass or two and the query is scanned again, and a pair whose two nearest points are (nearly) equally far can never be
+// certified at all -- at convergence the transform still jitters in its last bits, and ~70 pairs per million fail in every pass.
+// So a scan also keeps the whole neighbourhood it saw: S = every target point closer to p_ref than a radius T <= lim, if these are
+// at most 8.  Every point outside S is then >= T from p_ref, and while
+//     min over S of d(p, s) + delta < T
+// the nearest neighbour of p is a member of S: decided by the same fp32 (d2, row) comparison brute force makes, over <= 8 gathers
+// instead of a scan.  The room is now T - d1, several times L - d1.  Stored per pair: the sorted positions of S (PassArgs::certk,
+// 8 words, 0xFFFFFFFF: empty slot; the winner is one of them) and (T, hint) in PassArgs::hoodr.  Bit 0 of cert.w says that they are
+// valid, so every writer of a certificate invalidates them by writing an even word (cert_word).  A successful test moves the
+// reference to the current position: T <- T - delta and a fresh single certificate L = min(second nearest of S, T), exact bounds.
+// T follows the local point spacing: a scan counts ALL points within its T, kept or not, and leaves hint = T (6.5 / count)^0.4 for the
+// pair's next scan (the count grows with T^2 on a surface, T^3 in a noisy slab); a first scan starts from 2 x the previous pair's
+// distance.
 constexpr float kSlackFrac = 0.25f;      // (0.125 / 0.5 / 1.0 measured on the 1M surface pair and the 2M scan pair: within noise or worse)
+constexpr int kHoodSlots = 8;            // |S| <= 8, the winner included
+constexpr uint32_t kHoodNone = 0xFFFFFFFFu;
 
-// Certificate test for a two-candidate pair (cert.w = -L3).  In: the query's position, its distance to the current winner a
-// (d2a, rowa), the certificate.  True: the nearest neighbour is provably a or b; `swap` tells that b now wins (the caller makes b
-// the pair: position, record copy, pos2 <- a) and d2w / roww are the winner's.
-__device__ __forceinline__ bool two_candidate_test(const PassArgs &a, const TargetIndex &ix, uint32_t i, float px, float py, float pz, float d2a, int32_t rowa,
-                                                   const float4 &ce, int32_t &p2, float4 &qb, bool &swap)
+// cert.w for clear radius L (> 0; 0: none) and the neighbourhood flag: never above L
+__device__ __forceinline__ float cert_word(float L, bool hood)
 {
-    swap = false;
-    p2 = a.pos2[i];
-    if (p2 < 0 || (uint32_t)p2 >= ix.n) return false;
-    qb = ix.tq[p2];
-    const float d2b = dist2(px, py, pz, qb.x, qb.y, qb.z);
-    const float m2 = dist2(px, py, pz, ce.x, ce.y, ce.z);
-    if (!((__builtin_amdgcn_sqrtf(fmaxf(d2a, d2b)) + __builtin_amdgcn_sqrtf(m2)) * 1.000002f < -ce.w)) return false;
-    const int32_t rowb = __float_as_int(qb.w);
-    swap = (d2b < d2a) || (d2b == d2a && rowb < rowa);
+    const uint32_t u = __float_as_uint(L);
+    if (!(L > 0.0f)) return hood ? __uint_as_float(0xBF800001u) : 0.0f;      // -1 with the flag: neighbourhood only
+    return __uint_as_float(hood ? ((u - 1u) | 1u) : (u & ~1u));
+}
+
+// Neighbourhood test of pair i (its single certificate has failed or does not exist).  In: the query's position, delta^2 = m2 to the
+// reference, the current winner (sorted position, d2, row).  True: the nearest neighbour is provably a member of S; pos_w / d2w are
+// the winner's, and everything the change needs is stored (position, record copy, moved reference).
+__device__ __forceinline__ bool hood_test(const PassArgs &a, const TargetIndex &ix, uint32_t i, float px, float py, float pz, float m2,
+                                          int32_t pos_a, float d2a, int32_t rowa, int32_t &pos_w, float &d2w)
+{
+    const uint4 w0 = a.certk[2 * (size_t)i], w1 = a.certk[2 * (size_t)i + 1];
+    const float T = a.hoodr[i].x;
+    const uint32_t cand[kHoodSlots] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+    float4 q[kHoodSlots];
+#pragma unroll
+    for (int k = 0; k < kHoodSlots; k++) q[k] = ix.tq[min(cand[k], ix.n - 1u)];       // all gathers in flight at once
+    unsigned long long kw = ((unsigned long long)__float_as_uint(d2a) << 32) | (unsigned long long)(uint32_t)rowa;
+    uint32_t sec = 0x7f800000u;              // d2 bits of the second nearest of S
+    pos_w = pos_a;
+#pragma unroll
+    for (int k = 0; k < kHoodSlots; k++) {
+        const float d2 = dist2(px, py, pz, q[k].x, q[k].y, q[k].z);
+        if (cand[k] < ix.n && cand[k] != (uint32_t)pos_a && d2 == d2) {
+            const unsigned long long key = ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned long long)(uint32_t)__float_as_int(q[k].w);
+            if (key < kw) { sec = (uint32_t)(kw >> 32); kw = key; pos_w = (int32_t)cand[k]; }
+            else sec = min(sec, __float_as_uint(d2));
+        }
+    }
+    d2w = __uint_as_float((uint32_t)(kw >> 32));
+    const float dl = __builtin_amdgcn_sqrtf(m2);
+    if (!((__builtin_amdgcn_sqrtf(d2w) + dl) * 1.000002f < T)) return false;
+    if (pos_w != pos_a) {
+        a.pos_out[i] = pos_w;
+        store_pair_record(a, ix, i, pos_w);
+    }
+    // move the reference to p: everything outside S is >= T - delta from here
+    const float d1 = sqrtf(d2w) * 1.000001f;
+    const float Tn = (T - dl * 1.000001f) * 0.999999f;
+    const float L = fminf(sqrtf(__uint_as_float(sec)) * 0.999999f, Tn);
+    if (Tn > d1 * 1.001f) {
+        a.cert[i] = make_float4(px, py, pz, cert_word((L > d1) ? L : 0.0f, true));
+        a.hoodr[i].x = Tn;
+    } else if (pos_w != pos_a) {
+        a.cert[i].w = cert_word(0.0f, true);       // the moved radius would leave no room: reference and T stay, the old single certificate goes
+    }
     return true;
 }
 
 // One tile of 256 queries (i >= a.n: idle lane).  Called by k_search_cells (tile = block) and by k_pass_fused (the queries its
 // streaming phase could not certify).
+// from_list: the queries come from k_pass_fused's list -- their certificates have just failed there and are not tried again.
+// HOOD: this scan also keeps neighbourhoods (off in the passes right after the first big move, whose certificates the next
+// move invalidates anyway: the kernel then runs without the extra LDS and the scattered member stores).
+template <bool HOOD>
 __device__ __forceinline__ void cells_tile(const PassArgs &a, const TargetIndex &ix, const WorkLists &wl, const Affine &X, const uint32_t i,
-                                           const uint32_t shard, const bool count_uncertified)
+                                           const uint32_t shard, const bool from_list)
 {
     __shared__ float s_px[kPassThreads], s_py[kPassThreads], s_pz[kPassThreads];
     __shared__ unsigned long long s_key[kPassThreads];
@@ -347,6 +396,10 @@ __device__ __forceinline__ void cells_tile(const PassArgs &a, const TargetIndex 
     __shared__ uint16_t s_items[kPassThreads * 27];
     __shared__ uint32_t s_wsum[kPassThreads / 64 + 1];
     __shared__ uint32_t s_anyw[kPassThreads / 64];     // per-wave flags for block-wide "any" votes
+    constexpr int kHoodLds = HOOD ? kPassThreads : 1;
+    __shared__ float s_reach[kHoodLds];                // T of the query's neighbourhood (0: none wanted)
+    __shared__ uint32_t s_hcnt[kHoodLds];              // scanned points closer than T (the first 8 go straight to certk)
+    __shared__ uint32_t s_qi[kHoodLds];                // the query's index
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const bool active = i < a.n;
@@ -358,15 +411,16 @@ __device__ __forceinline__ void cells_tile(const PassArgs &a, const TargetIndex 
     b.d2 = inf; b.pos = -1; b.row = 0x7fffffff;
     uint32_t mask = 0;                 // cells of this query to scan this round, bit = kx + 3*ky + 9*kz
     uint32_t mask_rest = 0;            // probe: the other cells of the 3x3x3 block, scanned only if the 2x2x2 block cannot prove its best
-    bool defer = false, searched = false, probe = false, uncert = false;
+    bool defer = false, searched = false, probe = false, uncert = false, hood_ok = false;
     float lim = 0.f, lim_full = 0.f;   // everything outside the scanned cells is at least this far from the query
+    float reach = 0.f;                 // T of the neighbourhood this scan collects (0: none)
     if (active) {
         // Two memory round trips decide a certified pair: everything addressed by i first (the certificate is loaded
         // whether or not it will be needed), then the previous winner as one 16-byte load.
         const float x = a.in.x[i], y = a.in.y[i], z = a.in.z[i];
         const int32_t prev = a.pos_prev ? a.pos_prev[i] : -1;
         float clear = 0.0f, rx = 0.0f, ry = 0.0f, rz = 0.0f;                              // L (0: no certificate), p_ref
-        if (a.use_slack) { const float4 ce = a.cert[i]; rx = ce.x; ry = ce.y; rz = ce.z; clear = ce.w; }      // one 16-byte load
+        if (a.use_slack) { const float4 ce = a.cert[i]; rx = ce.x; ry = ce.y; rz = ce.z; clear = ce.w; }      // one 16-byte load (bit 0 of w: neighbourhood flag)
         px = xf_row(X.m + 0, x, y, z, 1.0f); py = xf_row(X.m + 4, x, y, z, 1.0f); pz = xf_row(X.m + 8, x, y, z, 1.0f);
         if (prev >= 0 && (uint32_t)prev < ix.n) {
             const float4 q = ix.tq[prev];
@@ -375,18 +429,14 @@ __device__ __forceinline__ void cells_tile(const PassArgs &a, const TargetIndex 
             if (d2 <= inf) { b.d2 = d2; b.pos = prev; b.row = row; }                      // (not NaN)
         }
         bool certified = false;
-        if (a.use_slack && b.pos >= 0 && clear >= 0.0f) {
+        if (a.use_slack && b.pos >= 0 && !from_list) {
             const float m2 = dist2(px, py, pz, rx, ry, rz);                               // delta^2
-            certified = (__builtin_amdgcn_sqrtf(b.d2) + __builtin_amdgcn_sqrtf(m2)) * 1.000002f < clear;     // 1-ulp roots, inside the margin
-        } else if (a.use_slack && b.pos >= 0) {
-            // two-candidate pair: the winner is the previous winner or its runner-up
-            int32_t p2; float4 qb; bool swap;
-            certified = two_candidate_test(a, ix, i, px, py, pz, b.d2, b.row, make_float4(rx, ry, rz, clear), p2, qb, swap);
-            if (certified && swap) {
-                a.pos2[i] = b.pos;
-                b.d2 = dist2(px, py, pz, qb.x, qb.y, qb.z); b.pos = p2; b.row = __float_as_int(qb.w);
-                a.pos_out[i] = p2;
-                store_pair_record(a, ix, i, p2);
+            certified = (__builtin_amdgcn_sqrtf(b.d2) + __builtin_amdgcn_sqrtf(m2)) * 1.000002f < clear;     // 1-ulp roots, inside the margin (clear <= 0: none)
+            if (!certified && (__float_as_uint(clear) & 1u) && a.certk) {
+                int32_t pw; float d2w;
+                if (hood_test(a, ix, i, px, py, pz, m2, b.pos, b.d2, b.row, pw, d2w)) {
+                    certified = hood_ok = true; b.pos = pw; b.d2 = d2w;
+                }
             }
         }
         if (certified) {
@@ -429,6 +479,7 @@ __device__ __forceinline__ void cells_tile(const PassArgs &a, const TargetIndex 
                                 if (g2 <= thr2) mask |= 1u << (kx + 3 * ky + 9 * kz);
                             }
                     s_cell0[tid] = (uint32_t)x0 | ((uint32_t)y0 << 10) | ((uint32_t)z0 << 20);
+                    reach = rb;            // (marks a scan; the radius is chosen below)
                 }
             }
             if (defer && b.pos >= 0 && ix.glevel > 0) {
@@ -479,6 +530,7 @@ __device__ __forceinline__ void cells_tile(const PassArgs &a, const TargetIndex 
                     lim_full = face - 2e-3f * ix.h;
                     probe = true;
                     defer = false;
+                    reach = __builtin_amdgcn_sqrtf(b.d2) * 1.00001f;
                 }
             }
             if (defer) {
@@ -490,7 +542,7 @@ __device__ __forceinline__ void cells_tile(const PassArgs &a, const TargetIndex 
             }
         }
     }
-    if (count_uncertified) {
+    if (!from_list) {
         // how many pairs had to be searched this pass: tells the host when the alignment has converged far enough for the fused
         // pass (engine.cpp, batch_eligible); word 1 behind each shard counter of the work list is free (counters sit 16 words apart)
         const unsigned long long mu = __ballot(uncert);
@@ -500,7 +552,13 @@ __device__ __forceinline__ void cells_tile(const PassArgs &a, const TargetIndex 
     s_pos[tid] = b.pos;
     s_key[tid] = (b.pos >= 0) ? (((unsigned long long)__float_as_uint(b.d2) << 32) | (unsigned long long)(uint32_t)b.row) : ~0ull;
     s_second[tid] = 0x7f800000u;
-    uint32_t mask_scanned = mask;      // every cell this query has scanned by the end (two-candidate certificates rescan them)
+    if (HOOD && reach > 0.0f && a.certk) {
+        // radius of the neighbourhood: the pair's hint from its last scan (but beyond the bound on the winner's distance), else twice
+        // the previous pair's distance; never beyond what the scan covers
+        const float hint = a.hoodr[i].y;
+        reach = fminf(probe ? lim_full : lim, hint > 0.0f ? fmaxf(hint, 1.01f * reach) : 2.0f * reach);      // (a probe: cut to what it has scanned in the end)
+    } else reach = 0.0f;
+    if (HOOD) { s_reach[tid] = reach; s_hcnt[tid] = 0; s_qi[tid] = i; }
     uint32_t total = 0, total_all = 0;
     for (int round = 0; round < 2; round++) {
     // block-wide exclusive prefix sum of the item counts
@@ -559,6 +617,7 @@ __device__ __forceinline__ void cells_tile(const PassArgs &a, const TargetIndex 
             const uint32_t cx = (c0 & 1023u) + (uint32_t)kx, cy = ((c0 >> 10) & 1023u) + (uint32_t)ky, cz = (c0 >> 20) + (uint32_t)kz;
             const uint2 rng = cell_range(ix, (spread3(cz) << 2) | (spread3(cy) << 1) | spread3(cx));
             const float qx = s_px[q], qy = s_py[q], qz = s_pz[q];
+            const float t2 = HOOD ? s_reach[q] * s_reach[q] : 0.0f;
             if (ix.dbg) atomicAdd(ix.dbg + 3, (unsigned long long)(rng.y - rng.x));
             for (uint32_t j = rng.x; j < rng.y; j += 4) {
                 float4 t4[4];
@@ -568,6 +627,10 @@ __device__ __forceinline__ void cells_tile(const PassArgs &a, const TargetIndex 
                 for (int k = 0; k < 4; k++) {
                     if (j + (uint32_t)k < rng.y) {
                         const float d2 = dist2(qx, qy, qz, t4[k].x, t4[k].y, t4[k].z);
+                        if (HOOD && d2 < t2) {                         // a member of the query's neighbourhood
+                            const uint32_t hs = atomicAdd(&s_hcnt[q], 1u);
+                            if (hs < (uint32_t)kHoodSlots) reinterpret_cast<uint32_t *>(a.certk)[(size_t)s_qi[q] * kHoodSlots + hs] = j + (uint32_t)k;
+                        }
                         if (d2 == d2) {
                             const unsigned long long key = ((unsigned long long)__float_as_uint(d2) << 32) |
                                                            (unsigned long long)(uint32_t)__float_as_int(t4[k].w);
@@ -599,10 +662,10 @@ __device__ __forceinline__ void cells_tile(const PassArgs &a, const TargetIndex 
     bool more = false;
     if (round == 0 && probe) {
         const float d1 = sqrtf(__uint_as_float((uint32_t)(s_key[tid] >> 32))) * 1.00001f;
-        if (!(d1 < lim)) { more = (mask_rest != 0); lim = lim_full; }
+        // (2 % of room at least: a best that only just clears the small block's face would hold a certificate no jitter survives)
+        if (!(d1 * 1.02f < lim)) { more = (mask_rest != 0); lim = lim_full; }
     }
     mask = more ? mask_rest : 0u;
-    mask_scanned |= mask;
     if (round == 1) break;
     {
         const unsigned long long anym = __ballot(more);
@@ -618,7 +681,9 @@ __device__ __forceinline__ void cells_tile(const PassArgs &a, const TargetIndex 
         // debug counters: [0] (query,cell) items, [1] certified, [2] cell scans, [6] probes, [7] handed to the walk in phase 1
         if (tid == 0) atomicAdd(ix.dbg + 0, (unsigned long long)total_all);
         const unsigned long long mc = __ballot(active && !defer && !searched && !probe), ms = __ballot(searched), mp = __ballot(probe), md = __ballot(defer);
+        const unsigned long long mh = __ballot(hood_ok);
         if (lane == 0) {
+            atomicAdd(ix.dbg + 8, (unsigned long long)__popcll(mh));
             atomicAdd(ix.dbg + 1, (unsigned long long)__popcll(mc)); atomicAdd(ix.dbg + 2, (unsigned long long)__popcll(ms));
             atomicAdd(ix.dbg + 6, (unsigned long long)__popcll(mp)); atomicAdd(ix.dbg + 7, (unsigned long long)__popcll(md));
         }
@@ -640,46 +705,34 @@ __device__ __forceinline__ void cells_tile(const PassArgs &a, const TargetIndex 
             // certificate for the following passes
             const float second = sqrtf(__uint_as_float(s_second[tid])) * 0.999999f;
             const float L = fminf(second, lim * 0.99999f);
-            float Lw = (L > d1) ? L : 0.0f;
-            if (!(L > d1 * 1.001f) && a.use_slack && a.pos2 && a.make_two_candidate) {
-                // (almost) no room between the two nearest points -- under 0.1 % of d1: at convergence the transform still jitters in
-                // its last bits, and a pair whose slack is below that jitter (~70 per million with slack < 5e-5 d1) would fail its
-                // certificate in every pass.  Scan this query's cells once more, alone, for the runner-up and the third-nearest
-                // distance (~2000 queries per million, in the passes that search them anyway)
-                unsigned long long k1 = ~0ull, k2 = ~0ull;      // (d2 bits << 32 | row) of the nearest and the runner-up
-                int32_t p1 = -1, p2 = -1;                       // ... and their sorted positions
-                uint32_t d3 = 0x7f800000u;                      // d2 bits of the third-nearest
-                const uint32_t c0 = s_cell0[tid];
-                for (uint32_t m = mask_scanned; m; m &= m - 1) {
-                    const int bit = __ffs((int)m) - 1;
-                    const int kz = bit / 9, ky = (bit - 9 * kz) / 3, kx = bit - 9 * kz - 3 * ky;
-                    const uint32_t cx = (c0 & 1023u) + (uint32_t)kx, cy = ((c0 >> 10) & 1023u) + (uint32_t)ky, cz = (c0 >> 20) + (uint32_t)kz;
-                    const uint2 rng = cell_range(ix, (spread3(cz) << 2) | (spread3(cy) << 1) | spread3(cx));
-                    for (uint32_t j = rng.x; j < rng.y; j++) {
-                        const float4 t = ix.tq[j];
-                        const float d2 = dist2(px, py, pz, t.x, t.y, t.z);
-                        if (!(d2 == d2)) continue;
-                        const unsigned long long kk = ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned long long)(uint32_t)__float_as_int(t.w);
-                        if (kk < k1) { d3 = min(d3, (uint32_t)(k2 >> 32)); k2 = k1; p2 = p1; k1 = kk; p1 = (int32_t)j; }
-                        else if (kk < k2) { d3 = min(d3, (uint32_t)(k2 >> 32)); k2 = kk; p2 = (int32_t)j; }
-                        else d3 = min(d3, __float_as_uint(d2));
-                    }
+            // the neighbourhood: everything the scan saw closer than T, if it fits (the winner is inside: T > d1)
+            bool hood = false;
+            const float Tq = HOOD ? fminf(s_reach[tid], lim) : 0.0f;         // (a probe collected up to its full block's bound: cut to what it scanned)
+            if (Tq > 0.0f) {
+                const uint32_t hc = s_hcnt[tid];
+                const float T = Tq * 0.99999f;
+                hood = T > d1 && hc >= 1u && hc <= (uint32_t)kHoodSlots;
+                if (hood) {
+                    uint32_t *slots = reinterpret_cast<uint32_t *>(a.certk) + (size_t)i * kHoodSlots;
+#pragma unroll
+                    for (int k = 1; k < kHoodSlots; k++) if ((uint32_t)k >= hc) slots[k] = kHoodNone;
                 }
-                if (k1 == key && p1 == s_pos[tid] && p2 >= 0) {
-                    const float db = sqrtf(__uint_as_float((uint32_t)(k2 >> 32))) * 1.000001f;
-                    const float L3 = fminf(sqrtf(__uint_as_float(d3)) * 0.999999f, lim * 0.99999f);
-                    if (L3 > db) { Lw = -L3; a.pos2[i] = p2; }
-                }
+                // the radius that would have held ~6.5 points: count ~ T^2.5 between a surface and a slab
+                const float scale = fminf(fmaxf(__powf(6.5f / ((float)hc + 0.5f), 0.4f), 0.4f), 1.5f);
+                a.hoodr[i] = make_float2(hood ? T : 0.0f, Tq * scale);
+                if (ix.dbg) atomicAdd(ix.dbg + (hood ? 9 : 10), 1ull);
             }
+            const float Lw = cert_word((L > d1) ? L : 0.0f, hood);
             a.cert[i] = make_float4(px, py, pz, Lw);
             store_pair_record(a, ix, i, s_pos[tid]);
         }
     }
 }
 
+template <bool HOOD>
 __global__ __launch_bounds__(kPassThreads) void k_search_cells(PassArgs a, TargetIndex ix, WorkLists wl)
 {
-    cells_tile(a, ix, wl, a.X, xcd_remap(blockIdx.x, gridDim.x) * kPassThreads + threadIdx.x, blockIdx.x & (kShards - 1), true);
+    cells_tile<HOOD>(a, ix, wl, a.X, xcd_remap(blockIdx.x, gridDim.x) * kPassThreads + threadIdx.x, blockIdx.x & (kShards - 1), false);
 }
 
 // ---------------------------------------------------------------------------
@@ -687,8 +740,8 @@ __global__ __launch_bounds__(kPassThreads) void k_search_cells(PassArgs a, Targe
 // certified, so the pass is a stream: per point 12 B position + 12 B normal + the pair's own 32-byte record copy + the
 // 16-byte certificate, all coalesced; certified pairs are accumulated on the spot (rows of func.cpp:51-58, 37 fp64 sums).
 // Separate search and accumulate kernels read the source twice and cost two launches.
-//   stream   grid-stride over tiles of 256 points: certificate test (the expressions of cells_tile, phase 1; two candidates where
-//            the pair carries them); a pair that fails goes to a list in LDS
+//   stream   grid-stride over tiles of 256 points: certificate test (the expressions of cells_tile, phase 1: single, then the
+//            neighbourhood); a pair that fails both goes to a list in LDS
 //   scan     the listed queries run through cells_tile, 256 at a time: exact scan, new pair, certificate and record copy
 //   settle   the listed queries once more: those that now have a pair are accumulated from their fresh record copy
 // A query the scan has to hand to the tree walk is appended to the work list and NOT accumulated (its record copy is
@@ -711,80 +764,112 @@ __device__ __forceinline__ void fused_accumulate(Acc &acc, const PassArgs &a, co
 #ifndef FUSED_WAVES
 #define FUSED_WAVES 2
 #endif
-__global__ __launch_bounds__(kPassThreads, FUSED_WAVES) void k_pass_fused(PassArgs a, TargetIndex ix, WorkLists wl)
+#ifndef COMPACT_WAVES
+#define COMPACT_WAVES 5
+#endif
+// ACC = true: the fused pass described above.  ACC = false: only the search part (stream + scan), for the passes of an alignment
+// that is still settling: the separate k_search_cells lets every block of 256 queries pay the latency of the whole scan machinery
+// for the dozen of them that need it; here a block streams several tiles and scans the failures 256 at a time (the walk and
+// k_accumulate follow as usual).  No normals, no record copies read, no sums: registers for 5 waves per SIMD.
+template <bool ACC>
+__global__ __launch_bounds__(kPassThreads, ACC ? FUSED_WAVES : COMPACT_WAVES) void k_pass_fused(PassArgs a, TargetIndex ix, WorkLists wl)
 {
     if (a.loop && a.loop->stop) return;
     __shared__ uint32_t s_list[kFusedList];
-    __shared__ uint32_t s_cnt;
+    __shared__ uint32_t s_cnt, s_total;
     const Affine X = a.loop ? a.loop->Xapply : a.X;
-    Acc acc; acc_zero(acc);
-    if (threadIdx.x == 0) s_cnt = 0;
+    Acc acc;
+    if (ACC) acc_zero(acc);
+    if (threadIdx.x == 0) { s_cnt = 0; s_total = 0; }
     __syncthreads();
+    const uint32_t shard = blockIdx.x & (kShards - 1);
+
+    // the listed queries: exact scan 256 at a time, then (ACC) the ones that now have a pair are accumulated from their fresh record copy
+    auto flush = [&]() {
+        const uint32_t cnt = s_cnt;
+        for (uint32_t base = 0; base < cnt; base += kPassThreads) {
+            const uint32_t e = base + threadIdx.x;
+            cells_tile<true>(a, ix, wl, X, e < cnt ? s_list[e] : 0xFFFFFFFFu, shard, true);
+            __syncthreads();
+        }
+        if (ACC) {
+            for (uint32_t base = 0; base < cnt; base += kPassThreads) {      // (each thread meets the entries it scanned itself)
+                const uint32_t e = base + threadIdx.x;
+                if (e >= cnt) continue;
+                const uint32_t i = s_list[e];
+                const float4 q = a.pairrec[2 * (size_t)i], nq = a.pairrec[2 * (size_t)i + 1];
+                if (nq.w != 0.0f) continue;                            // no target at all, or handed to the walk
+                const float x = a.in.x[i], y = a.in.y[i], z = a.in.z[i];
+                const float nx = a.in.nx[i], ny = a.in.ny[i], nz = a.in.nz[i];
+                const float px = xf_row(X.m + 0, x, y, z, 1.0f), py = xf_row(X.m + 4, x, y, z, 1.0f), pz = xf_row(X.m + 8, x, y, z, 1.0f);
+                fused_accumulate(acc, a, X, nx, ny, nz, px, py, pz, q, nq, dist2(px, py, pz, q.x, q.y, q.z));
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) { s_total += cnt; s_cnt = 0; }
+        __syncthreads();
+    };
+
     const uint32_t tiles = (a.n + kPassThreads - 1) / kPassThreads;
     const uint32_t tiles_p = ((tiles + 7u) / 8u) * 8u;
+    constexpr int kCheck = ACC ? 3 : 1;
+    int since = 0;
     // ---- stream (tile numbers are dealt so that each XCD works on one contiguous part of the sorted source)
     for (uint32_t t = blockIdx.x; t < tiles_p; t += gridDim.x) {
         const uint32_t i = xcd_remap(t, tiles_p) * kPassThreads + threadIdx.x;
-        if (i >= a.n) continue;
-        // one round trip: everything the common case (certified pair) needs
-        const float x = a.in.x[i], y = a.in.y[i], z = a.in.z[i];
-        const float nx = a.in.nx[i], ny = a.in.ny[i], nz = a.in.nz[i];
-        const float4 q = a.pairrec[2 * (size_t)i], nq = a.pairrec[2 * (size_t)i + 1];
-        const float4 ce = a.cert[i];
-        const float px = xf_row(X.m + 0, x, y, z, 1.0f), py = xf_row(X.m + 4, x, y, z, 1.0f), pz = xf_row(X.m + 8, x, y, z, 1.0f);
-        bool certified = false;
-        float d2 = 0.0f;
-        float4 qw = q, nqw = nq;                               // the pair that is accumulated
-        if (nq.w == 0.0f) {                                    // a fresh copy of the previous winner (same bits as tq[prev])
-            d2 = dist2(px, py, pz, q.x, q.y, q.z);
-            if (ce.w >= 0.0f) {
-                const float m2 = dist2(px, py, pz, ce.x, ce.y, ce.z);
-                certified = (__builtin_amdgcn_sqrtf(d2) + __builtin_amdgcn_sqrtf(m2)) * 1.000002f < ce.w;      // cells_tile, phase 1
+        if (i < a.n) {
+            // one round trip: everything the common case (certified pair) needs
+            const float x = a.in.x[i], y = a.in.y[i], z = a.in.z[i];
+            float nx = 0.f, ny = 0.f, nz = 0.f;
+            float4 q, nq = make_float4(0.f, 0.f, 0.f, 2.0f);
+            int32_t pa = -1;
+            if (ACC) {
+                nx = a.in.nx[i]; ny = a.in.ny[i]; nz = a.in.nz[i];
+                q = a.pairrec[2 * (size_t)i]; nq = a.pairrec[2 * (size_t)i + 1];      // a fresh copy (w = 0) has the bits of tq[prev]
             } else {
-                // two-candidate pair (see kSlackFrac): the winner is the previous winner or its runner-up
-                int32_t p2; float4 qb; bool swap;
-                certified = two_candidate_test(a, ix, i, px, py, pz, d2, __float_as_int(q.w), ce, p2, qb, swap);
-                if (certified && swap) {
-                    a.pos2[i] = a.pos_prev[i];
-                    a.pos_out[i] = p2;
-                    qw = ix.tn[2 * (size_t)p2]; nqw = ix.tn[2 * (size_t)p2 + 1];
-                    a.pairrec[2 * (size_t)i] = qw; a.pairrec[2 * (size_t)i + 1] = nqw;
-                    d2 = dist2(px, py, pz, qw.x, qw.y, qw.z);
+                pa = a.pos_prev[i];
+                if ((uint32_t)pa < ix.n) { q = ix.tq[pa]; nq.w = 0.0f; }
+            }
+            const float4 ce = a.cert[i];
+            const float px = xf_row(X.m + 0, x, y, z, 1.0f), py = xf_row(X.m + 4, x, y, z, 1.0f), pz = xf_row(X.m + 8, x, y, z, 1.0f);
+            bool certified = false;
+            float d2 = 0.0f;
+            float4 qw = q, nqw = nq;                               // the pair that is accumulated
+            if (nq.w == 0.0f) {
+                d2 = dist2(px, py, pz, q.x, q.y, q.z);
+                const float m2 = dist2(px, py, pz, ce.x, ce.y, ce.z);
+                certified = (__builtin_amdgcn_sqrtf(d2) + __builtin_amdgcn_sqrtf(m2)) * 1.000002f < ce.w;          // cells_tile, phase 1
+                if (!certified && d2 <= __int_as_float(0x7f800000) && (__float_as_uint(ce.w) & 1u) && a.certk) {
+                    // the neighbourhood certificate: the winner is a member of the set the last scan kept
+                    if (ACC) pa = a.pos_prev[i];
+                    int32_t pw; float d2w;
+                    if ((uint32_t)pa < ix.n && hood_test(a, ix, i, px, py, pz, m2, pa, d2, __float_as_int(q.w), pw, d2w)) {
+                        certified = true;
+                        if (ACC && pw != pa) { qw = ix.tn[2 * (size_t)pw]; nqw = ix.tn[2 * (size_t)pw + 1]; }
+                        d2 = d2w;
+                    }
                 }
             }
+            if (certified) {
+                a.d2_out[i] = d2;                                  // refreshed distance of the (possibly changed) pair
+                if (ACC) fused_accumulate(acc, a, X, nx, ny, nz, px, py, pz, qw, nqw, d2);
+            } else {
+                s_list[atomicAdd(&s_cnt, 1u)] = i;                 // (room for a whole tile: see the flush below)
+            }
         }
-        if (certified) {
-            a.d2_out[i] = d2;                                  // refreshed distance of the (possibly swapped) pair
-            fused_accumulate(acc, a, X, nx, ny, nz, px, py, pz, qw, nqw, d2);
-        } else {
-            const uint32_t k = atomicAdd(&s_cnt, 1u);
-            if (k < (uint32_t)kFusedList) s_list[k] = i;
-            else { a.pairrec[2 * (size_t)i + 1].w = 2.0f; sl_push(wl.work, blockIdx.x & (kShards - 1), i); }      // overflow: the pass will be repeated
+        // room for kCheck more tiles?  (uniform: everyone reads s_cnt after the barrier; the fused pass of a converged alignment has
+        // next to no failures and pays the barrier only every third tile)
+        if (++since == kCheck) {
+            since = 0;
+            __syncthreads();
+            if (s_cnt > (uint32_t)(kFusedList - kCheck * kPassThreads)) flush();
         }
     }
     __syncthreads();
-    const uint32_t cnt = min(s_cnt, (uint32_t)kFusedList);
-    if (threadIdx.x == 0 && s_cnt) atomicAdd(wl.work.counts + (blockIdx.x & (kShards - 1)) * kShardStride + 1, s_cnt);          // pairs that had to be searched (see cells_tile)
-    // ---- scan
-    for (uint32_t base = 0; base < cnt; base += kPassThreads) {
-        const uint32_t e = base + threadIdx.x;
-        cells_tile(a, ix, wl, X, e < cnt ? s_list[e] : 0xFFFFFFFFu, blockIdx.x & (kShards - 1), false);
-        __syncthreads();
-    }
-    // ---- settle (each thread meets the entries it scanned itself)
-    for (uint32_t base = 0; base < cnt; base += kPassThreads) {
-        const uint32_t e = base + threadIdx.x;
-        if (e >= cnt) continue;
-        const uint32_t i = s_list[e];
-        const float4 q = a.pairrec[2 * (size_t)i], nq = a.pairrec[2 * (size_t)i + 1];
-        if (nq.w != 0.0f) continue;                            // no target at all, or handed to the walk
-        const float x = a.in.x[i], y = a.in.y[i], z = a.in.z[i];
-        const float nx = a.in.nx[i], ny = a.in.ny[i], nz = a.in.nz[i];
-        const float px = xf_row(X.m + 0, x, y, z, 1.0f), py = xf_row(X.m + 4, x, y, z, 1.0f), pz = xf_row(X.m + 8, x, y, z, 1.0f);
-        fused_accumulate(acc, a, X, nx, ny, nz, px, py, pz, q, nq, dist2(px, py, pz, q.x, q.y, q.z));
-    }
-    __syncthreads();
-    acc_block_reduce_store(acc, a.partials, gridDim.x);
+    flush();
+    // pairs that had to be searched (see cells_tile)
+    if (threadIdx.x == 0 && s_total) atomicAdd(wl.work.counts + shard * kShardStride + 1, s_total);
+    if (ACC) acc_block_reduce_store(acc, a.partials, gridDim.x);
 }
 
 // ---------------------------------------------------------------------------
@@ -972,7 +1057,7 @@ __global__ __launch_bounds__(kWalkThreads, 6) void k_search_walk(PassArgs a, Tar
             // everything not scanned was pruned beyond (nearest + pad): same certificate as in k_search_cells
             const float d1 = sqrtf(__uint_as_float((uint32_t)(bkey >> 32)));
             const float L = fminf(sqrtf(__uint_as_float(second)) * 0.999999f, (d1 + pad) * 0.99999f);
-            a.cert[i] = make_float4(px, py, pz, (L > d1 * 1.000001f) ? L : 0.0f);
+            a.cert[i] = make_float4(px, py, pz, cert_word((L > d1 * 1.000001f) ? L : 0.0f, false));      // (an even word: no neighbourhood)
         }
         if (lane == 0) {
             a.pos_out[i] = bpos;
@@ -1342,8 +1427,9 @@ uint32_t walk_blocks_full(const WorkLists &wl)
 
 // stage: 0 = whole pass (cells, walk, accumulate); 1 = cells and accumulate only (the host expects an empty work list
 // and repairs the pass otherwise); 2 = the repair: walk and accumulate
+// compact_blocks > 0: the search runs as k_pass_fused<false> on that many blocks (sparse scans), else as k_search_cells
 void launch_pass_tree_split(const PassArgs &a_in, const TargetIndex &ix, const WorkLists &wl, int acc_blocks, uint32_t walk_blocks,
-                            int stage, hipStream_t s, hipEvent_t *ev)
+                            int stage, int compact_blocks, hipStream_t s, hipEvent_t *ev)
 {
     PassArgs a = a_in;
     a.refresh_records = (stage != 1) ? 1 : 0;      // a stage-1 pass may still be repaired: its accumulate must not settle stale copies
@@ -1352,7 +1438,11 @@ void launch_pass_tree_split(const PassArgs &a_in, const TargetIndex &ix, const W
     const uint32_t nb = (a.n + kPassThreads - 1) / kPassThreads;
     const uint32_t nbp = ((nb + 7u) / 8u) * 8u;
     if (ev) hipEventRecord(ev[0], s);
-    if (stage != 2 && nbp) hipLaunchKernelGGL(k_search_cells, dim3(nbp), dim3(kPassThreads), 0, s, a, ix, wl);      // (nbp == 0: a rank whose share is empty)
+    if (stage != 2 && nbp) {      // (nbp == 0: a rank whose share is empty)
+        if (compact_blocks > 0) hipLaunchKernelGGL(k_pass_fused<false>, dim3(min((uint32_t)compact_blocks, nbp)), dim3(kPassThreads), 0, s, a, ix, wl);
+        else if (a.make_hood) hipLaunchKernelGGL(k_search_cells<true>, dim3(nbp), dim3(kPassThreads), 0, s, a, ix, wl);
+        else hipLaunchKernelGGL(k_search_cells<false>, dim3(nbp), dim3(kPassThreads), 0, s, a, ix, wl);
+    }
     if (ev) hipEventRecord(ev[1], s);
     if (ev) hipEventRecord(ev[2], s);
     if (stage != 1 && nbp) {
@@ -1389,7 +1479,7 @@ void launch_final_reduce(const double *partials, int blocks, double *out_dev, do
 
 void launch_pass_fused(const PassArgs &a, const TargetIndex &ix, const WorkLists &wl, int blocks, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_pass_fused, dim3(blocks), dim3(kPassThreads), 0, s, a, ix, wl);
+    hipLaunchKernelGGL(k_pass_fused<true>, dim3(blocks), dim3(kPassThreads), 0, s, a, ix, wl);
 }
 
 void launch_reduce_solve(const double *partials, int blocks, double *out_dev, int mode, LoopState *loop, LoopConfig cfg, LoopRecord *ring, int ring_len,

@@ -135,9 +135,10 @@ struct PassArgs {
     float4 *pairrec;                    // TREE: per pair, its own copy of the target's (point, normal) record (2 float4)
     int32_t budget_walk;                // this pass's thread-per-query walk runs with a visit budget + retry launch (see k_search_walk)
     int32_t refresh_records;            // k_accumulate may replace stale copies (0 in a pass that may still be repaired)
-    float4 *cert;                       // per pair: (ref.xyz, clear radius L around ref; L = 0: no certificate; L < 0: two-candidate certificate, -L3)
-    int32_t *pos2;                      // per pair with a two-candidate certificate: sorted position of the runner-up
-    int32_t make_two_candidate;         // this pass may create two-candidate certificates (it always honours existing ones)
+    float4 *cert;                       // per pair: (ref.xyz, clear radius L around ref; L <= 0: no single certificate); bit 0 of L's word: certk[i] is valid
+    uint4 *certk;                       // per pair, 2 x uint4: the neighbourhood certificate's members (8 sorted positions; see hood_test in kernels_pass.hip)
+    float2 *hoodr;                      // ... its radius T and the radius hint for the pair's next scan
+    int32_t make_hood;                  // k_search_cells keeps neighbourhoods in this pass (existing ones are honoured either way)
     int32_t use_slack;                  // 0 on the first pass of an alignment (certificates not valid yet)
     const LoopState *loop;              // device-driven loop: the transform comes from here (null: from X above)
 };
@@ -148,8 +149,9 @@ void launch_pass_indexed(const PassArgs &a, const float4 *tn /* pair records */,
 // ev: null, or 5 events recorded before cells / after cells / (same again) / after walk / after accumulate
 // walk_blocks: grid of k_search_walk (any size is correct; 0 = one thread per possible list entry)
 // stage: 0 = cells, walk, accumulate; 1 = cells, accumulate (walk skipped); 2 = walk, accumulate (repair of a stage-1 pass)
+// compact_blocks > 0: the cell search runs as the streaming, compacting kernel (k_pass_fused<false>) on that many blocks
 void launch_pass_tree_split(const PassArgs &a, const TargetIndex &ix, const WorkLists &wl, int acc_blocks, uint32_t walk_blocks,
-                            int stage, hipStream_t s, hipEvent_t *ev);
+                            int stage, int compact_blocks, hipStream_t s, hipEvent_t *ev);
 void launch_pass_tree_first(const PassArgs &a, const TargetIndex &ix, const WorkLists &wl, int acc_blocks, hipStream_t s, hipEvent_t *ev);
 uint32_t walk_blocks_full(const WorkLists &wl);
 uint32_t shard_capacity(uint32_t n_points);

@@ -346,12 +346,16 @@ class Engine:
                     error=(self._L.symmicp_last_error(self._h) or b"").decode() if st != OK else "")
 
     def certificates(self):
-        """diagnostic: (cert [n_loc, 4], runner_up [n_loc]) of this rank's share, in its sorted order"""
+        """diagnostic: (cert [n_loc, 4], neighbourhood members [n_loc, 8] as target rows, neighbourhood radius T [n_loc],
+        winner row [n_loc]) of this rank's share, in its sorted order"""
         n = self.local_count()
         ce = np.zeros((n, 4), np.float32)
-        ru = np.zeros(n, np.int32)
-        self._chk(self._L.symmicp_get_certificates(self._h, _fptr(ce), ru.ctypes.data_as(C.POINTER(C.c_int32)), C.c_size_t(n)))
-        return ce, ru
+        hood = np.zeros((n, 8), np.uint32)
+        T = np.zeros(n, np.float32)
+        win = np.zeros(n, np.int32)
+        self._chk(self._L.symmicp_get_certificates(self._h, _fptr(ce), hood.ctypes.data_as(C.POINTER(C.c_uint32)), _fptr(T),
+                                                   win.ctypes.data_as(C.POINTER(C.c_int32)), C.c_size_t(n)))
+        return ce, hood, T, win
 
     def transform(self):
         X = np.zeros(16, np.float32)

@@ -159,9 +159,10 @@ int symmicp_get_correspondences(symmicp_ctx *ctx, int32_t *idx, float *d2, size_
 /* current (transformed) source points / normals of this rank's share, original row order, packed AoS. */
 int symmicp_get_source(symmicp_ctx *ctx, float *xyz, float *nrm, size_t cap);
 /* diagnostic (SYMMICP_CORR_TREE): the pair certificates of this rank's share in its sorted order: cert4 [n_loc][4] = position of the
- * query when its pair was last searched + the clear radius L (0: none; < 0: two-candidate certificate, -L3); runner_up (may be
- * NULL) [n_loc]: sorted target position of the second candidate where L < 0 */
-int symmicp_get_certificates(symmicp_ctx *ctx, float *cert4, int32_t *runner_up, size_t cap);
+ * query when its pair was last searched + the clear radius L (<= 0: no single certificate; bit 0 of the word: the neighbourhood is
+ * valid); hood8 (may be NULL) [n_loc][8]: the neighbourhood's members as target rows (0xFFFFFFFF: empty); hood_radius (may be NULL)
+ * [n_loc]: its radius T; winner_row (may be NULL) [n_loc]: the pair's current target row (-1: none) */
+int symmicp_get_certificates(symmicp_ctx *ctx, float *cert4, uint32_t *hood8, float *hood_radius, int32_t *winner_row, size_t cap);
 size_t symmicp_local_source_count(const symmicp_ctx *ctx);
 size_t symmicp_local_source_offset(const symmicp_ctx *ctx);
 

@@ -876,6 +876,48 @@ def test_pair_certificates_stay_exact_under_small_and_large_moves(sym, oracle):
             assert np.array_equal(d2, rd)
 
 
+@pytest.mark.parametrize("workload", ["c4", "c5"])
+def test_neighbourhood_certificates_hold_what_they_claim(sym, oracle, workload):
+    """Neighbourhood certificates (hood_test in kernels_pass.hip): a scan keeps every target point closer to the query's
+    reference position than T; later passes decide the pair among those points alone.  Let an alignment converge from the
+    identity (its later passes drift by fractions of the point spacing: single certificates run out of room and the
+    neighbourhoods take over), check every pass against
+    the exact nearest neighbours, and check the stored certificates themselves against a k-d tree: no target point outside
+    the kept set may lie within T of the reference, no point other than the winner within L."""
+    from scipy.spatial import cKDTree
+    from symmicp import synth
+    d = synth.c4_surface(50000) if workload == "c4" else synth.c5_scan(64 * 800)
+    tree = cKDTree(d["tgt"].astype(np.float64))
+    used = 0
+    with sym.Engine(mode=sym.MODE_PAPER, corr=sym.CORR_TREE, apply=sym.APPLY_INCREMENTAL) as e:
+        e.set_target(d["tgt"], d["tgt_n"])
+        e.set_source(d["src"], d["src_n"])
+        e.begin()                  # from the identity: the alignment's own convergence is the drift
+        for it in range(14):
+            e.step()
+            idx, d2 = e.correspondences()
+            p, _ = e.source()
+            ri, rd = oracle.nn_grid(p, d["tgt"])
+            bad = np.nonzero(idx != ri)[0]
+            assert bad.size == 0, (workload, it, bad[:5], idx[bad[:5]], ri[bad[:5]])
+            assert np.array_equal(d2, rd)
+            ce, hood, T, win = e.certificates()
+            flag = (ce[:, 3].view(np.uint32) & 1).astype(bool)
+            T = T.astype(np.float64)
+            sel = np.nonzero(flag & (win >= 0))[0]
+            used += sel.size
+            for i in sel[:: max(1, sel.size // 400)]:
+                inside = set(tree.query_ball_point(ce[i, :3].astype(np.float64), T[i] * (1 - 2e-5)))
+                kept = set(int(r) for r in hood[i] if r != 0xFFFFFFFF)
+                assert int(win[i]) in kept
+                assert inside <= kept, (workload, it, i, sorted(inside - kept), T[i])
+            single = np.nonzero((ce[:, 3] > 0) & (win >= 0))[0]
+            for i in single[:: max(1, single.size // 400)]:
+                inside = set(tree.query_ball_point(ce[i, :3].astype(np.float64), float(ce[i, 3]) * (1 - 2e-5)))
+                assert inside <= {int(win[i])}, (workload, it, i, inside, win[i], ce[i])
+    assert used > 0, "no neighbourhood certificate was ever created"
+
+
 @pytest.mark.parametrize("apply_mode", ["INCREMENTAL", "CUMULATIVE"])
 def test_identity_pairs_and_distances_on_request(sym, oracle, cat, apply_mode):
     """identity pairing (myicp.cpp:130): rows pair up by index; the per-pair distances are evaluated on request"""
