@@ -951,6 +951,7 @@ static int run_pass(symmicp_ctx *c, const float Xapply[16], bool from_cur, bool 
                 if (walk_blocks < 256u) walk_blocks = 256u;
                 if (walk_blocks > 8192u) walk_blocks = 8192u;
             }
+            if (!first && c->last_list_len == -2) walk_blocks = 16384u;
             if (std::getenv("SYMMICP_WALK_FULL_GRID")) walk_blocks = 0;
             // Once an alignment has converged the work list stays empty (every pair is certified or settled by the cell
             // scan), and an empty walk launch still costs ~6 us of a ~50 us pass.  So after a pass with an empty list the
@@ -1050,6 +1051,9 @@ static int run_pass(symmicp_ctx *c, const float Xapply[16], bool from_cur, bool 
     std::memcpy(c->last.s, c->h_sums, sizeof(double) * kNSum);
     if (c->cfg.corr == SYMMICP_CORR_TREE) c->last.s[kNSum - 1] = c->last.s[kNSum - 2] = c->last.s[kNSum - 3] = 0.0;      // those slots carried the list length and the number of searched pairs, not sums
     c->last_list_len = list_len;
+    // the packet first pass has no work list; the pass after it (the cloud has just moved by its whole misalignment) always has one:
+    // -2 = "expect a list" (no optimistic skip of the walk, which would only be repaired; a mid-sized walk grid)
+    if (first && c->cfg.corr == SYMMICP_CORR_TREE && c->target_surface_like) c->last_list_len = -2;
     c->st.passes++;
     return SYMMICP_OK;
 }

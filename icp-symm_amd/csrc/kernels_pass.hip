@@ -818,7 +818,10 @@ __global__ __launch_bounds__(kPassThreads, ACC ? FUSED_WAVES : COMPACT_WAVES) vo
     for (uint32_t t = blockIdx.x; t < tiles_p; t += gridDim.x) {
         const uint32_t i = xcd_remap(t, tiles_p) * kPassThreads + threadIdx.x;
         if (i < a.n) {
-            // one round trip: everything the common case (certified pair) needs
+            // one round trip: everything the common case (certified pair) needs.  (Measured and dropped: fetching the next tile before
+            // working on this one -- no gain, the pass already moves its 76 B per point at ~3.2 TB/s; letting the last block to finish
+            // reduce and solve in place of k_reduce_solve -- the device-scope fences it needs cost every block an L2 write-back, 79 us
+            // per pass instead of 27 + 12.)
             const float x = a.in.x[i], y = a.in.y[i], z = a.in.z[i];
             float nx = 0.f, ny = 0.f, nz = 0.f;
             float4 q, nq = make_float4(0.f, 0.f, 0.f, 2.0f);
@@ -1433,7 +1436,7 @@ void launch_pass_tree_split(const PassArgs &a_in, const TargetIndex &ix, const W
 {
     PassArgs a = a_in;
     a.refresh_records = (stage != 1) ? 1 : 0;      // a stage-1 pass may still be repaired: its accumulate must not settle stale copies
-    static const uint32_t wave_mode_max = getenv("SYMMICP_WAVE_MODE_MAX") ? (uint32_t)atol(getenv("SYMMICP_WAVE_MODE_MAX")) : 200000u;   // work lists longer than this use one thread per query
+    static const uint32_t wave_mode_max = getenv("SYMMICP_WAVE_MODE_MAX") ? (uint32_t)atol(getenv("SYMMICP_WAVE_MODE_MAX")) : 20000u;   // work lists longer than this use one thread per query (the 48k-entry list after the first move of the 1M surface pair: 115 -> 85 us)
     // all shard counters are zero here: cleared by the previous pass's final reduce
     const uint32_t nb = (a.n + kPassThreads - 1) / kPassThreads;
     const uint32_t nbp = ((nb + 7u) / 8u) * 8u;
