@@ -283,7 +283,7 @@ static_assert(2 * kFrontCap * sizeof(uint32_t) == kPktStack * 2 * sizeof(float4)
 #define PKT_WAVES 4
 #endif
 template <bool DBG>
-__global__ __launch_bounds__(64, PKT_WAVES) void k_search_packet(PassArgs a, TargetIndex ix)
+__global__ __launch_bounds__(64, PKT_WAVES) void k_search_packet(PassArgs a, TargetIndex ix, uint32_t chunk)
 {
     __shared__ float4 s_buf[kPktStack][2];         // BFS: two frontier buffers; DFS fallback: the stack
     __shared__ float s_sb[4][8];                   // bounding boxes of the four 16-query sub-groups
@@ -294,17 +294,21 @@ __global__ __launch_bounds__(64, PKT_WAVES) void k_search_packet(PassArgs a, Tar
     const float inf = __int_as_float(0x7f800000);
     if (lane < kMortonBits + 2) s_off[lane] = ix.olevel_off[lane];
     __syncthreads();
-    const uint32_t npk = (a.n + 63u) >> 6;
+    const uint32_t npk = a.pkt_tab ? a.pkt_count : (a.n + 63u) >> 6;
     constexpr bool CERT = false;              // the first pass leaves no certificates (the cloud is about to move by its whole misalignment)
     const float pad = 0.0f;
     const float4 *__restrict__ tq = ix.tq;
     const float4 *__restrict__ onodes = ix.onodes;
     PktCounters cn = {0, 0, 0, 0, 0, 0, 0};
-    for (uint32_t pk = xcd_remap(blockIdx.x, gridDim.x); pk < npk; pk += gridDim.x) {
+    for (uint32_t slot = xcd_remap_chunked(blockIdx.x, chunk); slot < npk; slot += gridDim.x) {
+        // a packet: `count` consecutive queries from `first` (the host's table: widest first), or 64 as they lie
+        uint32_t first = slot * 64u, count = 64u;
+        if (a.pkt_tab) { const uint2 e = a.pkt_tab[slot]; first = e.x; count = e.y; }
+        const uint32_t pk = slot;
         unsigned long long t_start = 0;
         if (DBG) t_start = __builtin_amdgcn_s_memrealtime();
-        const uint32_t i = pk * 64u + (uint32_t)lane;
-        const bool active = i < a.n;
+        const uint32_t i = first + (uint32_t)lane;
+        const bool active = (uint32_t)lane < count && i < a.n;
         float px = 0.f, py = 0.f, pz = 0.f;
         PktBest b;
         b.d2 = inf; b.second = 0x7f800000u; b.pos = -1;
@@ -500,6 +504,32 @@ __global__ __launch_bounds__(64, PKT_WAVES) void k_search_packet(PassArgs a, Tar
     }
 }
 
+// Predicted cost of a packet: the radius of its 64 queries around their centroid (invariant under the rigid transform the
+// alignment applies).  Packets that straddle a jump of the Morton curve are several times wider than the rest and take several times
+// as many sweep steps; the host starts the packets longest-first (engine.cpp, set_source).
+__global__ __launch_bounds__(64) void k_packet_radius(CloudSoA src, uint32_t n, float *__restrict__ radius2)
+{
+    const uint32_t i = blockIdx.x * 64u + threadIdx.x;
+    const bool active = i < n;
+    const float x = active ? src.x[i] : 0.f, y = active ? src.y[i] : 0.f, z = active ? src.z[i] : 0.f;
+    float sx = x, sy = y, sz = z, cnt = active ? 1.f : 0.f;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        sx += __shfl_xor(sx, off, 64); sy += __shfl_xor(sy, off, 64); sz += __shfl_xor(sz, off, 64); cnt += __shfl_xor(cnt, off, 64);
+    }
+    const float cx = sx / cnt, cy = sy / cnt, cz = sz / cnt;
+    float r2 = active ? dist2(x, y, z, cx, cy, cz) : 0.f;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) r2 = fmaxf(r2, __shfl_xor(r2, off, 64));
+    if (threadIdx.x == 0) radius2[blockIdx.x] = r2;
+}
+
+void launch_packet_radius(const CloudSoA &src, uint32_t n, float *radius2, hipStream_t s)
+{
+    const uint32_t npk = (n + 63u) / 64u;
+    if (npk) hipLaunchKernelGGL(k_packet_radius, dim3(npk), dim3(64), 0, s, src, n, radius2);
+}
+
 // first pass of an alignment: no previous pairs, every query is searched -- packets over the whole (sorted) share
 void launch_accumulate(const PassArgs &a, const float4 *tn, int blocks, hipStream_t s);
 
@@ -507,13 +537,14 @@ void launch_pass_tree_first(const PassArgs &a_in, const TargetIndex &ix, const W
 {
     PassArgs a = a_in;
     a.refresh_records = 1;
-    const uint32_t npk = (a.n + 63u) / 64u;
-    const uint32_t nbp = ((npk + 7u) / 8u) * 8u;
+    const uint32_t npk = a.pkt_tab ? a.pkt_count : (a.n + 63u) / 64u;
+    static const uint32_t chunk = getenv("SYMMICP_PACKET_CHUNK") ? (uint32_t)atol(getenv("SYMMICP_PACKET_CHUNK")) : 64u;      // packets per chunk (xcd_remap_chunked)
+    const uint32_t nbp = ((npk + 8u * chunk - 1u) / (8u * chunk)) * (8u * chunk);
     if (ev) { hipEventRecord(ev[0], s); hipEventRecord(ev[1], s); hipEventRecord(ev[2], s); }
     static const uint32_t lds_pad = getenv("SYMMICP_PACKET_LDS_PAD") ? (uint32_t)atol(getenv("SYMMICP_PACKET_LDS_PAD")) : 0u;      // occupancy experiments
-    if (!nbp) { /* empty share */ }
-    else if (ix.dbg) hipLaunchKernelGGL((k_search_packet<true>), dim3(nbp), dim3(64), lds_pad, s, a, ix);
-    else hipLaunchKernelGGL((k_search_packet<false>), dim3(nbp), dim3(64), lds_pad, s, a, ix);
+    if (!npk) { /* empty share */ }
+    else if (ix.dbg) hipLaunchKernelGGL((k_search_packet<true>), dim3(nbp), dim3(64), lds_pad, s, a, ix, chunk);
+    else hipLaunchKernelGGL((k_search_packet<false>), dim3(nbp), dim3(64), lds_pad, s, a, ix, chunk);
     if (ev) hipEventRecord(ev[3], s);
     launch_accumulate(a, ix.tn, acc_blocks, s);
     if (ev) hipEventRecord(ev[4], s);

@@ -17,3 +17,19 @@ for s in (0, 2):
     # concurrency over time
     grid = np.linspace(0, end.max(), 11)
     print("   packets running at t: " + " ".join("%d" % ((st <= g) & (end > g)).sum() for g in grid))
+# per-XCD share (xcd_remap: XCD x works on the x-th eighth of the packets, in order)
+t_all = np.fromfile(sys.argv[1], dtype=np.uint64).reshape(-1, 2)
+n = int(np.nonzero(t_all[:, 0])[0].max()) + 1
+npad = (n + 7) // 8 * 8
+st_all = t_all[:n, 0].astype(np.int64) * 10; du_all = (t_all[:n, 1] >> np.uint64(32)).astype(np.int64) * 10
+print("per eighth of the packets: work (sum of durations, ms) and last end (us)")
+for x in range(8):
+    lo, hi = x * npad // 8, min(n, (x + 1) * npad // 8)
+    m = st_all[lo:hi] != 0
+    print("   eighth %d: %6.1f ms  end %7.0f us   mean dur %5.0f us" % (x, du_all[lo:hi][m].sum() / 1e6, ((st_all[lo:hi] + du_all[lo:hi])[m].max() - t0) / 1e3, du_all[lo:hi][m].mean() / 1e3))
+# the slowest packets: did they overflow into the depth-first fallback?
+ga = (t_all[:n, 1] & np.uint64(1)).astype(bool); po = ((t_all[:n, 1] >> np.uint64(8)) & np.uint64(0xFFFFFF)).astype(np.int64)
+order = np.argsort(-du_all)
+print("slowest 12: " + "; ".join("%.0fus%s steps %d" % (du_all[k] / 1e3, "*" if ga[k] else "", po[k]) for k in order[:12]) + "   (*: depth-first fallback)")
+print("fallback packets: %d, duration mean %.0f us, sum %.1f ms of %.1f ms; others: mean %.0f us, 99%% %.0f us, max %.0f us" % (ga.sum(), du_all[ga].mean() / 1e3, du_all[ga].sum() / 1e6, du_all.sum() / 1e6, du_all[~ga].mean() / 1e3, np.quantile(du_all[~ga], .99) / 1e3, du_all[~ga].max() / 1e3))
+print("duration quantiles (us): " + " ".join("%g:%.0f" % (q, np.quantile(du_all, q) / 1e3) for q in (.5, .9, .99, .999, 1)))
