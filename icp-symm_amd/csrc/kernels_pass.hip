@@ -730,9 +730,11 @@ __device__ __forceinline__ void cells_tile(const PassArgs &a, const TargetIndex 
 }
 
 template <bool HOOD>
-__global__ __launch_bounds__(kPassThreads) void k_search_cells(PassArgs a, TargetIndex ix, WorkLists wl)
+__global__ __launch_bounds__(kPassThreads) void k_search_cells(PassArgs a, TargetIndex ix, WorkLists wl, uint32_t chunk)
 {
-    cells_tile<HOOD>(a, ix, wl, a.X, xcd_remap(blockIdx.x, gridDim.x) * kPassThreads + threadIdx.x, blockIdx.x & (kShards - 1), false);
+    // (tiles dealt to the XCDs in chunks of kCellsChunk: the regions of a cloud differ in cost, see xcd_remap_chunked; tiles past the end idle)
+    const uint32_t tile = xcd_remap_chunked(blockIdx.x, chunk);
+    cells_tile<HOOD>(a, ix, wl, a.X, tile * kPassThreads + threadIdx.x, tile & (kShards - 1), false);      // (the shard follows the tile: the lists' capacity assumes an even spread)
 }
 
 // ---------------------------------------------------------------------------
@@ -1451,8 +1453,12 @@ void launch_pass_tree_split(const PassArgs &a_in, const TargetIndex &ix, const W
     if (ev) hipEventRecord(ev[0], s);
     if (stage != 2 && nbp) {      // (nbp == 0: a rank whose share is empty)
         if (compact_blocks > 0) hipLaunchKernelGGL(k_pass_fused<false>, dim3(min((uint32_t)compact_blocks, nbp)), dim3(kPassThreads), 0, s, a, ix, wl);
-        else if (a.make_hood) hipLaunchKernelGGL(k_search_cells<true>, dim3(nbp), dim3(kPassThreads), 0, s, a, ix, wl);
-        else hipLaunchKernelGGL(k_search_cells<false>, dim3(nbp), dim3(kPassThreads), 0, s, a, ix, wl);
+        else {
+            static const uint32_t chunk = getenv("SYMMICP_CELLS_CHUNK") ? (uint32_t)atol(getenv("SYMMICP_CELLS_CHUNK")) : 16u;      // tiles per chunk
+            const uint32_t nbc = ((nb + 8u * chunk - 1u) / (8u * chunk)) * (8u * chunk);
+            if (a.make_hood) hipLaunchKernelGGL(k_search_cells<true>, dim3(nbc), dim3(kPassThreads), 0, s, a, ix, wl, chunk);
+            else hipLaunchKernelGGL(k_search_cells<false>, dim3(nbc), dim3(kPassThreads), 0, s, a, ix, wl, chunk);
+        }
     }
     if (ev) hipEventRecord(ev[1], s);
     if (ev) hipEventRecord(ev[2], s);
