@@ -813,12 +813,15 @@ __global__ __launch_bounds__(kPassThreads, ACC ? FUSED_WAVES : COMPACT_WAVES) vo
     };
 
     const uint32_t tiles = (a.n + kPassThreads - 1) / kPassThreads;
-    const uint32_t tiles_p = ((tiles + 7u) / 8u) * 8u;
+    // ACC: one contiguous eighth of the tiles per XCD (uniform work, best locality); search only: chunks of 16 tiles (the regions of a
+    // cloud differ in cost: xcd_remap_chunked)
+    constexpr uint32_t kTileChunk = 16;
+    const uint32_t tiles_p = ACC ? ((tiles + 7u) / 8u) * 8u : ((tiles + 8u * kTileChunk - 1u) / (8u * kTileChunk)) * (8u * kTileChunk);
     constexpr int kCheck = ACC ? 3 : 1;
     int since = 0;
     // ---- stream (tile numbers are dealt so that each XCD works on one contiguous part of the sorted source)
     for (uint32_t t = blockIdx.x; t < tiles_p; t += gridDim.x) {
-        const uint32_t i = xcd_remap(t, tiles_p) * kPassThreads + threadIdx.x;
+        const uint32_t i = (ACC ? xcd_remap(t, tiles_p) : xcd_remap_chunked(t, kTileChunk)) * kPassThreads + threadIdx.x;
         if (i < a.n) {
             // one round trip: everything the common case (certified pair) needs.  (Measured and dropped: fetching the next tile before
             // working on this one -- no gain, the pass already moves its 76 B per point at ~3.2 TB/s; letting the last block to finish
