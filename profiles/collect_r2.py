@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Turn the output of profiles/collect_r2.sh (gpurun_out/r2_final/) into the committed round-2 summaries:
 
-  profiles/r2_bench_*.json              the bench lines (default 30 steps, the driver's 20/5, host loop, C3 tree / brute, C5 8M, identity 8M)
+  profiles/r2_bench_*.json              the bench lines (default 30 steps, the driver's 20/5, host loop, C3 tree / brute, C5 8M / 2M, identity 8M)
   profiles/r2_kernel_stats.csv          rocprofv3 --kernel-trace --stats summary of `python3 bench.py --no-cpu-baseline`
   profiles/r2_identity_kernel_stats.csv the same for the 8M-point identity pass
   profiles/r2_pmc.json                  per-regime PMC figures of the default bench command, read by bench.py:
@@ -91,14 +91,16 @@ def regimes(dirname, counter, scale):
 
 def main():
     os.makedirs(OUT, exist_ok=True)
-    for name in ("bench_default", "bench_driver_20", "bench_host_loop", "bench_c3_100k_tree", "bench_c3_100k_brute", "bench_c5_8M_tree", "bench_identity_8M"):
+    pmc_only = "--pmc-only" in sys.argv          # on the GPU box, between the PMC passes and the bench lines (collect_r2.sh)
+    for name in () if pmc_only else ("bench_default", "bench_driver_20", "bench_host_loop", "bench_c3_100k_tree", "bench_c3_100k_brute", "bench_c5_8M_tree", "bench_c5_2M_tree", "bench_identity_8M"):
         line = [l for l in open(os.path.join(SRC, name + ".json")).read().splitlines() if l.startswith("{")][-1]
         json.loads(line)
         with open(os.path.join(OUT, "r2_" + name + ".json"), "w") as f:
             f.write(line + "\n")
-    shutil.copy(one(os.path.join(SRC, "trace", "*", "*_kernel_stats.csv")), os.path.join(OUT, "r2_kernel_stats.csv"))
-    shutil.copy(one(os.path.join(SRC, "trace_identity", "*", "*_kernel_stats.csv")), os.path.join(OUT, "r2_identity_kernel_stats.csv"))
-    for tag, log in (("", "trace.log"), ("identity_", "trace_identity.log")):
+    if not pmc_only:
+        shutil.copy(one(os.path.join(SRC, "trace", "*", "*_kernel_stats.csv")), os.path.join(OUT, "r2_kernel_stats.csv"))
+        shutil.copy(one(os.path.join(SRC, "trace_identity", "*", "*_kernel_stats.csv")), os.path.join(OUT, "r2_identity_kernel_stats.csv"))
+    for tag, log in () if pmc_only else (("", "trace.log"), ("identity_", "trace_identity.log")):
         line = [l for l in open(os.path.join(SRC, log)).read().splitlines() if l.startswith("{") and '"metric"' in l][-1]
         with open(os.path.join(OUT, "r2_%sbench_under_rocprof.json" % tag), "w") as f:
             f.write(line + "\n")
