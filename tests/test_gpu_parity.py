@@ -918,6 +918,45 @@ def test_neighbourhood_certificates_hold_what_they_claim(sym, oracle, workload):
     assert used > 0, "no neighbourhood certificate was ever created"
 
 
+def synth_rotation(deg, axis):
+    from symmicp import synth
+    return synth.rotation(deg, axis)
+
+
+def test_certificates_on_a_lattice_of_near_ties(sym, oracle):
+    """The hard case for pair and neighbourhood certificates: a lattice target (with duplicated points: exact ties, lowest row
+    wins) and source points near cell centres, face centres and edge midpoints -- 8, 4 and 2 nearly equidistant candidates, i.e.
+    single certificates with next to no room and neighbourhoods that just fit (8 members) or do not.  Every pass of a
+    converging alignment must give the pairs brute force gives."""
+    rng = np.random.default_rng(5)
+    g = np.stack(np.meshgrid(np.arange(14), np.arange(14), np.arange(14), indexing="ij"), -1).reshape(-1, 3).astype(np.float32)
+    tgt = np.concatenate([g, g[rng.permutation(len(g))[:400]]])[rng.permutation(len(g) + 400)].astype(np.float32) * np.float32(0.05)
+    inner = g[(g.max(1) < 13)]
+    src = np.concatenate([inner + 0.5, inner + np.float32([0.5, 0.5, 0]), inner + np.float32([0.5, 0, 0]), inner]).astype(np.float32) * np.float32(0.05)
+    src = src + rng.normal(0, 2e-5, src.shape).astype(np.float32)
+    nrm = rng.normal(size=src.shape).astype(np.float32); nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    tn = rng.normal(size=tgt.shape).astype(np.float32); tn /= np.linalg.norm(tn, axis=1, keepdims=True)
+    G = np.eye(4, dtype=np.float32)
+    G[:3, :3] = np.float32(synth_rotation(0.02, (1, 2, 3)))
+    G[:3, 3] = np.float32([3e-4, -2e-4, 1e-4])
+    hoods = 0
+    with sym.Engine(mode=sym.MODE_P2P, corr=sym.CORR_TREE, apply=sym.APPLY_INCREMENTAL) as e:
+        e.set_target(tgt, tn)
+        e.set_source(src, nrm)
+        e.begin(G)
+        for it in range(10):
+            e.step()
+            idx, d2 = e.correspondences()
+            p, _ = e.source()
+            ri, rd = oracle.nn_grid(p, tgt)
+            bad = np.nonzero(idx != ri)[0]
+            assert bad.size == 0, (it, bad[:5], idx[bad[:5]], ri[bad[:5]], d2[bad[:5]], rd[bad[:5]])
+            assert np.array_equal(d2, rd)
+            ce, hood, T, win = e.certificates()
+            hoods += int(((ce[:, 3].view(np.uint32) & 1) != 0).sum())
+    assert hoods > 0
+
+
 @pytest.mark.parametrize("apply_mode", ["INCREMENTAL", "CUMULATIVE"])
 def test_identity_pairs_and_distances_on_request(sym, oracle, cat, apply_mode):
     """identity pairing (myicp.cpp:130): rows pair up by index; the per-pair distances are evaluated on request"""
