@@ -1101,6 +1101,13 @@ static int run_pass(symmicp_ctx *c, const float Xapply[16], bool from_cur, bool 
 // transform from device memory, and the loop test of myicp.cpp:123 sets a stop flag every later kernel of the batch
 // honours.  The host solve stays the reference: anything but a clean, well-conditioned solve, and any pass that needs
 // the tree walk, stops the batch and the host loop takes that iteration (LOOP_HOST_SOLVE / LOOP_REDO_PASS).
+// work lists up to this length are walked inside a device-driven loop (straggler stage); longer ones go back to the host, which sizes the walk
+static constexpr uint32_t kLoopListLimit = 8192;
+// Scans are what the fused pass is slow at (two waves per SIMD: a dense cell's dependent loads are not hidden; ~6 ns per scanned pair
+// against 0.3 in k_search_cells), so a run starts once the last pass searched under 0.4 % of the pairs and under 8192 of them -- the
+// separate kernels win above that whatever the cloud's size (8M scan pair: 328 us fused against 150 + 80 at 30 k scans) -- and is left
+// (LOOP_SLOW) at four times as many.
+static uint32_t loop_scan_limit(uint32_t n) { const uint32_t f = n / 256; return f < 8192u ? f : 8192u; }
 static bool batch_eligible(const symmicp_ctx *c)
 {
     static const char *env = std::getenv("SYMMICP_HOST_LOOP");            // "1": never batch (A/B runs, tests)
@@ -1113,15 +1120,18 @@ static bool batch_eligible(const symmicp_ctx *c)
     if (c->host_passes_since_bailout < 2) return false;
     const bool incr = resolved_apply(c->cfg) == SYMMICP_APPLY_INCREMENTAL;
     if (c->cfg.corr == SYMMICP_CORR_IDENTITY) return true;
-    // TREE: the fused pass is for converged alignments: nothing left for the tree walk and under 0.4 % of the pairs searched again
+    // TREE: the fused pass is for converged alignments: under 0.4 % of the pairs searched again, a short work list at most (stragglers
+    // outside the overlap: real scans always have some)
     if (c->cfg.corr == SYMMICP_CORR_TREE)
-        return !incr && c->last_list_len == 0 && c->last_uncertified >= 0 && c->last_uncertified <= (long long)(c->n_s_total / 256) && c->cert && !std::getenv("SYMMICP_NO_CERT");
+        return !incr && c->last_list_len >= 0 && c->last_list_len <= (long long)kLoopListLimit && c->last_uncertified >= 0 &&
+               c->last_uncertified <= (long long)(loop_scan_limit(c->n_s_total) / (c->last_list_len > 0 ? 2 : 1)) && c->cert && !std::getenv("SYMMICP_NO_CERT");      // (the straggler stage costs two launches per pass)
     return false;
 }
 
 // Runs up to `want` iterations on the device.  On return c->iters, c->X and c->last describe the last COMPLETE pass, exactly as
 // if symmicp_step had been called (c->iters - iters_before) times; diffs_before[k] = the diff the reference prints before
 // iteration iters_before + 1 + k.  *small_step: the increment rule ended the alignment.
+static constexpr int kListBlocks = 8;      // partial columns of the straggler stage
 static int run_batch(symmicp_ctx *c, int want, float *diffs_before, int *n_done, bool *small_step)
 {
     *n_done = 0;
@@ -1135,7 +1145,13 @@ static int run_batch(symmicp_ctx *c, int want, float *diffs_before, int *n_done,
     lc.diff_threshold = c->cfg.diff_threshold; lc.eps_rotation = c->cfg.eps_rotation; lc.eps_translation = c->cfg.eps_translation;
     lc.nrm_w = (c->cfg.mode == SYMMICP_MODE_QUIRKS) ? 1.0f : 0.0f;
     for (int k = 0; k < 3; k++) lc.pivot[k] = c->pivot[k];
-    lc.uncertified_limit = c->n_s_total / 64;
+    lc.uncertified_limit = 4 * loop_scan_limit(c->n_s_total);
+    // stragglers: while passes leave a work list, every fused pass is followed by the walk over the list and the accumulation of its
+    // pairs (two more launches per pass, ~10 us); decided per chunk of passes from the lists the previous chunk left.  Without the stage
+    // a list that turns up stops the loop: the host redoes that pass and the next batch starts with the stage.
+    static const bool no_stage = std::getenv("SYMMICP_NO_LOOP_STRAGGLERS") != nullptr;      // A/B runs
+    bool stragglers = tree && c->last_list_len > 0 && !no_stage;
+    lc.list_limit = kLoopListLimit;
     if (lc.max_iters > c->cfg.max_iters) lc.max_iters = c->cfg.max_iters;
     const int it0 = c->iters;
     float X0[16];
@@ -1163,18 +1179,26 @@ static int run_batch(symmicp_ctx *c, int want, float *diffs_before, int *n_done,
         const int nb = (int)(((vec4 ? c->n_loc / 4 : c->n_loc) + kPassThreads - 1) / kPassThreads);
         blocks = nb < id_cap ? (nb > 0 ? nb : 1) : id_cap;
     }
+    const int fused_blocks_full = blocks;
     c->pass_blocks = blocks;
     uint32_t *counters = tree ? c->wl_count : nullptr;
     // The record of the last complete pass is in d_sums: solve from it, then (pass, reduce, [all-reduce,] solve) per iteration.
     // Passes are enqueued in chunks of 4, 8, 16, ... with one look at the loop state between chunks: a loop that stops early
     // (convergence, a pass that has to be redone) leaves at most one chunk of no-op launches behind.
     if (c->timing == 1 && c->ev_used + want > symmicp_ctx::kEvRing) flush_events(c);
-    int enq = 0, chunk = 4;
+    int enq = 0, chunk = 4, n_stage = 0;
     bool first_chunk = true;
     while (enq < want) {
         const int nq = (want - enq < chunk) ? want - enq : chunk;
         const int it_before = first_chunk ? it0 : c->h_loop->iters;
         const int ev_used0 = c->ev_used;
+        // this chunk's variant: partial columns, what a non-empty list means to the solve
+        // (with the stage: 512 partial columns in all, k_reduce_solve's fast path)
+        const int fused_blocks = (stragglers && fused_blocks_full + kListBlocks > 512) ? 512 - kListBlocks : fused_blocks_full;
+        blocks = fused_blocks + (stragglers ? kListBlocks : 0);
+        a.partial_cols = stragglers ? (uint32_t)blocks : 0u;
+        a.partial_col0 = (uint32_t)fused_blocks;
+        lc.walk_in_loop = stragglers ? 1 : 0;
         if (first_chunk) launch_reduce_solve(c->partials, blocks, c->d_sums, 2, c->d_loop, lc, c->h_ring_dev, symmicp_ctx::kRing, counters, c->stream);
         for (int p = 0; p < nq; p++) {
             hipEvent_t *ev = nullptr;
@@ -1183,7 +1207,10 @@ static int run_batch(symmicp_ctx *c, int want, float *diffs_before, int *n_done,
                 c->ev_split[c->ev_used] = 1;
                 hipEventRecord(ev[0], c->stream);
             }
-            if (tree) launch_pass_fused(a, c->ix, c->wl, blocks, c->stream);
+            if (tree) {
+                launch_pass_fused(a, c->ix, c->wl, fused_blocks, c->stream);
+                if (stragglers) launch_loop_stragglers(a, c->ix, c->wl, kListBlocks, c->stream);
+            }
             else launch_pass_identity(a, c->tgt, blocks, vec4, c->stream);
             if (ev) { hipEventRecord(ev[4], c->stream); c->ev_used++; }
             if (c->comm || blocks > 512) {
@@ -1224,7 +1251,13 @@ static int run_batch(symmicp_ctx *c, int want, float *diffs_before, int *n_done,
         // stop are dropped
         const int ran = (c->h_loop->iters - it_before) + (c->h_loop->reason == LOOP_REDO_PASS ? 1 : 0);
         if (c->timing == 1 && ran >= 0 && ev_used0 + ran < c->ev_used) c->ev_used = ev_used0 + ran;
+        if (stragglers) n_stage += c->h_loop->iters - it_before;
         if (c->h_loop->stop) break;
+        if (tree && !no_stage) {
+            // the stage stays (or comes) on while any pass of this chunk left a list
+            stragglers = false;
+            for (int k = it_before + 1; k <= c->h_loop->iters; k++) stragglers = stragglers || c->h_ring[k % symmicp_ctx::kRing].list_len > 0;
+        }
         chunk *= 2;
     }
     const LoopState &hl = *c->h_loop;
@@ -1236,14 +1269,16 @@ static int run_batch(symmicp_ctx *c, int want, float *diffs_before, int *n_done,
         std::memcpy(c->last.s, c->h_ring[it1 % symmicp_ctx::kRing].sums, sizeof(double) * kNSum);
         std::memcpy(c->X, c->h_ring[(it1 - 1) % symmicp_ctx::kRing].X, sizeof(float) * 16);      // transform the last complete pass applied
         c->st.passes += it1 - it0;
+        c->st.loop_passes += it1 - it0;
+        c->st.loop_straggler_passes += n_stage;
     }
     (void)X0;
     c->iters = it1;
-    c->last_list_len = tree ? 0 : -1;
+    c->last_list_len = tree ? (it1 > it0 ? (long long)c->h_ring[it1 % symmicp_ctx::kRing].list_len : c->last_list_len) : -1;
     *n_done = it1 - it0;
     *small_step = hl.reason == LOOP_DONE && hl.small_step != 0;
     if (tree && it1 > it0) c->last_uncertified = c->h_ring[it1 % symmicp_ctx::kRing].pad;
-    if (std::getenv("SYMMICP_DEBUG_HOST")) std::fprintf(stderr, "[symmicp host] batch: %d of %d passes on the device (%d enqueued), reason %d\n", it1 - it0, want, enq, hl.reason);
+    if (std::getenv("SYMMICP_DEBUG_HOST")) std::fprintf(stderr, "[symmicp host] batch: %d of %d passes on the device (%d enqueued), reason %d, %d with the straggler stage, list after %lld\n", it1 - it0, want, enq, hl.reason, n_stage, (long long)c->last_list_len);
     if (hl.reason == LOOP_SLOW) c->host_passes_since_bailout = 1;      // one host pass, then look again
     if (hl.reason == LOOP_REDO_PASS || hl.reason == LOOP_HOST_SOLVE) {
         c->host_passes_since_bailout = 0;
@@ -1687,6 +1722,7 @@ int symmicp_reset_stats(symmicp_ctx *c)
     c->st.last_pass_ms = c->st.sum_pass_ms = 0.0;
     c->st.passes = 0;
     c->st.passes_timed = 0;
+    c->st.loop_passes = c->st.loop_straggler_passes = 0;
     for (int k = 0; k < 8; k++) { c->st.kernel_ms[k] = 0.0; c->st.kernel_launches[k] = 0; c->st.pass_ms_head[k] = 0.0; }
     return SYMMICP_OK;
 }

@@ -105,7 +105,7 @@ __device__ __forceinline__ double wave_sum_to_lane63(double x)
 
 // block reduction: DPP wave sums, then LDS across the 4 waves; fixed order -> deterministic.
 // record k of block b lands at partials[k * nblocks + b] (transposed: the final reduce reads it coalesced)
-__device__ __forceinline__ void acc_block_reduce_store(Acc &a, double *partials, uint32_t nblocks)
+__device__ __forceinline__ void acc_block_reduce_store(Acc &a, double *partials, uint32_t nblocks, uint32_t col)
 {
     __shared__ double red[(kPassThreads / 64) * kNSum];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -121,9 +121,11 @@ __device__ __forceinline__ void acc_block_reduce_store(Acc &a, double *partials,
 #pragma unroll
             for (int w = 0; w < kPassThreads / 64; w++) s += red[w * kNSum + threadIdx.x];
         }
-        partials[(size_t)threadIdx.x * nblocks + blockIdx.x] = s;
+        partials[(size_t)threadIdx.x * nblocks + col] = s;
     }
 }
+
+__device__ __forceinline__ void acc_block_reduce_store(Acc &a, double *partials, uint32_t nblocks) { acc_block_reduce_store(a, partials, nblocks, blockIdx.x); }
 
 // ---------------------------------------------------------------------------
 // pass, identity pairing (what the reference does: myicp.cpp:130)
@@ -877,7 +879,7 @@ __global__ __launch_bounds__(kPassThreads, ACC ? FUSED_WAVES : COMPACT_WAVES) vo
     flush();
     // pairs that had to be searched (see cells_tile)
     if (threadIdx.x == 0 && s_total) atomicAdd(wl.work.counts + shard * kShardStride + 1, s_total);
-    if (ACC) acc_block_reduce_store(acc, a.partials, gridDim.x);
+    if (ACC) acc_block_reduce_store(acc, a.partials, a.partial_cols ? a.partial_cols : gridDim.x);
 }
 
 // ---------------------------------------------------------------------------
@@ -934,6 +936,10 @@ template <bool BUDGETED>
 __global__ __launch_bounds__(kWalkThreads, 6) void k_search_walk(PassArgs a, TargetIndex ix, WorkLists wl, ShardList list, uint32_t kWaveModeMax,
                                                                  uint32_t budget)
 {
+    if (a.loop) {                                   // straggler stage of a device-driven loop
+        if (a.loop->stop) return;
+        a.X = a.loop->Xapply;
+    }
     __shared__ uint32_t fr[1][2][kWaveFrontier];
     __shared__ uint32_t pre[kShards + 1];
     sl_prefix(list, pre);
@@ -1117,6 +1123,42 @@ __global__ __launch_bounds__(kPassThreads) void k_accumulate(PassArgs a, const f
 //   word 1 of shard t   pairs searched this pass, counted per shard  -> searched
 //   word 2 of a list    appends dropped because a shard was full     -> dropped  (work + retry list; must be 0)
 // Results are valid in every lane.
+// Straggler stage of a device-driven loop (after k_pass_fused and k_search_walk): the pairs of the work list's queries -- the fused pass
+// left them out and marked their record copies stale -- are gathered, their copies refreshed, their rows summed into `gridDim.x` partial
+// columns behind the fused pass's.  Launched whether or not the list is empty (the columns must be written).
+__global__ __launch_bounds__(kPassThreads) void k_accumulate_list(PassArgs a, const float4 *__restrict__ tn, ShardList list)
+{
+    if (a.loop) {
+        if (a.loop->stop) return;
+        a.X = a.loop->Xapply;
+    }
+    Acc acc; acc_zero(acc);
+    // block b: shards b, b + gridDim.x, ...; its waves take them in turn (a list is a handful of entries: what counts is that the
+    // counters and entries of all shards are requested side by side, not one shard after the other)
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (uint32_t shard = blockIdx.x + gridDim.x * wave; shard < (uint32_t)kShards; shard += gridDim.x * (kPassThreads / 64)) {
+        const uint32_t cnt = min(list.counts[shard * kShardStride], list.cap);
+        for (uint32_t e = lane; e < cnt; e += 64) {
+            const uint32_t i = list.items[(size_t)shard * list.cap + e];
+            const float x = a.in.x[i], y = a.in.y[i], z = a.in.z[i];
+            const float nx = a.in.nx[i], ny = a.in.ny[i], nz = a.in.nz[i];
+            const int32_t pos = a.pos_out[i];
+            float4 q = make_float4(0.f, 0.f, 0.f, 0.f), nq = make_float4(0.f, 0.f, 0.f, 1.f);
+            if (pos >= 0) { q = tn[2 * (size_t)pos]; nq = tn[2 * (size_t)pos + 1]; }
+            a.pairrec[2 * (size_t)i] = q; a.pairrec[2 * (size_t)i + 1] = nq;
+            if (nq.w != 0.0f) continue;                   // no target for this point
+            const float px = xf_row(a.X.m + 0, x, y, z, 1.0f), py = xf_row(a.X.m + 4, x, y, z, 1.0f), pz = xf_row(a.X.m + 8, x, y, z, 1.0f);
+            const float npx = xf_row(a.X.m + 0, nx, ny, nz, a.X.nrm_w), npy = xf_row(a.X.m + 4, nx, ny, nz, a.X.nrm_w),
+                        npz = xf_row(a.X.m + 8, nx, ny, nz, a.X.nrm_w);
+            const float d2 = dist2(px, py, pz, q.x, q.y, q.z);
+            if (a.max_d2 > 0.0f && d2 > a.max_d2) continue;
+            if (a.min_ndot > -1.0f && (npx * nq.x + npy * nq.y) + npz * nq.z < a.min_ndot) continue;
+            acc_pair(acc, px, py, pz, npx, npy, npz, q.x, q.y, q.z, nq.x, nq.y, nq.z, d2, a.pivot, a.p2p);
+        }
+    }
+    acc_block_reduce_store(acc, a.partials, a.partial_cols, a.partial_col0 + blockIdx.x);
+}
+
 __device__ __forceinline__ void read_list_words(const uint32_t *cnt, int t, uint32_t &len, uint32_t &searched, uint32_t &dropped)
 {
     uint32_t v = cnt[t * kShardStride], u = cnt[t * kShardStride + 1];
@@ -1277,15 +1319,18 @@ __global__ __launch_bounds__(512) void k_reduce_solve(const double *__restrict__
     if (t != 0) return;
     int it = ls.iters;
     if (!solve_only) {
-        if (cfg.tree && s_len > 0u) { loop->stop = 1; loop->reason = LOOP_REDO_PASS; return; }
+        // a non-empty work list: handled by the straggler stage of this very pass, or the pass has to be redone by the host; dropped
+        // appends (0xFFFFFFFF) always go back
+        if (cfg.tree && s_len > 0u && (!cfg.walk_in_loop || s_len == 0xFFFFFFFFu)) { loop->stop = 1; loop->reason = LOOP_REDO_PASS; return; }
         it += 1;                                                        // this pass is complete
         loop->iters = it;
         LoopRecord &r = ring[it % ring_len];
         for (int k = 0; k < kNSum; k++) { const double v = (k >= kNAcc) ? 0.0 : s_sum[k]; r.sums[k] = v; if (REDUCE) out_dev[k] = v; }
         r.solved = 0;
         r.pad = (int32_t)s_unc;
+        r.list_len = (int32_t)s_len; r.reserved = 0;
         // many pairs had to be searched again (the cloud moved): the separate kernels do that faster; this pass is complete
-        if (cfg.tree && s_unc > cfg.uncertified_limit) { loop->stop = 1; loop->reason = LOOP_SLOW; return; }
+        if (cfg.tree && (s_unc > cfg.uncertified_limit || (cfg.walk_in_loop && s_len > cfg.list_limit))) { loop->stop = 1; loop->reason = LOOP_SLOW; return; }
     }
     // ---- myicp.cpp:123
     const float diff = (float)s_sum[33];
@@ -1500,6 +1545,14 @@ void launch_final_reduce(const double *partials, int blocks, double *out_dev, do
 void launch_pass_fused(const PassArgs &a, const TargetIndex &ix, const WorkLists &wl, int blocks, hipStream_t s)
 {
     hipLaunchKernelGGL(k_pass_fused<true>, dim3(blocks), dim3(kPassThreads), 0, s, a, ix, wl);
+}
+
+void launch_loop_stragglers(const PassArgs &a, const TargetIndex &ix, const WorkLists &wl, int list_blocks, hipStream_t s)
+{
+    // (short lists: the wave-per-entry regime; anything above the threshold strides one thread per entry over this grid)
+    static const uint32_t wave_mode_max = getenv("SYMMICP_WAVE_MODE_MAX") ? (uint32_t)atol(getenv("SYMMICP_WAVE_MODE_MAX")) : 20000u;
+    hipLaunchKernelGGL(k_search_walk<false>, dim3(512), dim3(kWalkThreads), 0, s, a, ix, wl, wl.work, wave_mode_max, 0xFFFFFFFFu);
+    hipLaunchKernelGGL(k_accumulate_list, dim3(list_blocks), dim3(kPassThreads), 0, s, a, ix.tn, wl.work);
 }
 
 void launch_reduce_solve(const double *partials, int blocks, double *out_dev, int mode, LoopState *loop, LoopConfig cfg, LoopRecord *ring, int ring_len,

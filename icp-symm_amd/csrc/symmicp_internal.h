@@ -103,6 +103,9 @@ struct LoopConfig {
     float diff_threshold, eps_rotation, eps_translation, nrm_w;
     float pivot[3];
     uint32_t uncertified_limit;   // TREE: more pairs than this searched in a pass -> back to the separate kernels (LOOP_SLOW)
+    int32_t walk_in_loop;         // TREE: the batch runs k_search_walk + k_accumulate_list behind every fused pass: a non-empty work list is
+                                  // handled there (it stops the loop otherwise: LOOP_REDO_PASS)
+    uint32_t list_limit;          // ... unless it is longer than this (LOOP_SLOW: the host sizes the walk for long lists)
 };
 struct LoopRecord {          // one per pass, host-mapped
     double sums[SYMMICP_NSUM];       // the pass's record (after the exchange over ranks)
@@ -111,6 +114,7 @@ struct LoopRecord {          // one per pass, host-mapped
     int32_t status;                  // status of that solve
     int32_t solved;                  // 1: increment / X are valid (the loop went on)
     int32_t pad;                     // (pairs searched in this pass)
+    int32_t list_len, reserved;      // work-list length of this pass (queries handed to the tree walk)
 };
 
 struct PassArgs {
@@ -141,6 +145,7 @@ struct PassArgs {
     int32_t make_hood;                  // k_search_cells keeps neighbourhoods in this pass (existing ones are honoured either way)
     int32_t use_slack;                  // 0 on the first pass of an alignment (certificates not valid yet)
     const LoopState *loop;              // device-driven loop: the transform comes from here (null: from X above)
+    uint32_t partial_cols, partial_col0;   // partial records: columns in all (0: the grid's size) and this launch's first column
     const uint2 *pkt_tab;               // first pass (packets): (first query, count <= 64) per packet in start order (null: 64 as they lie)
     uint32_t pkt_count;
 };
@@ -162,6 +167,8 @@ void launch_final_reduce(const double *partials, int blocks, double *out_dev, do
                          unsigned long long seq, uint32_t *counters_to_clear, int keep_nonempty, hipStream_t s);
 // fused pass of a converged alignment (k_pass_fused) and the device-side end of a pass (k_reduce_solve): see kernels_pass.hip
 void launch_pass_fused(const PassArgs &a, const TargetIndex &ix, const WorkLists &wl, int blocks, hipStream_t s);
+// device-driven loop, straggler stage behind a fused pass: the work list through the tree walk, then its pairs into `list_blocks` more partial columns
+void launch_loop_stragglers(const PassArgs &a, const TargetIndex &ix, const WorkLists &wl, int list_blocks, hipStream_t s);
 // mode 0: reduce + check + solve (single GPU); 1: the record is already in out_dev (after the all-reduce); 2: solve only (start of a batch)
 void launch_reduce_solve(const double *partials, int blocks, double *out_dev, int mode, LoopState *loop, LoopConfig cfg, LoopRecord *ring, int ring_len,
                          uint32_t *counters_to_clear, hipStream_t s);

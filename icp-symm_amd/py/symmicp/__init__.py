@@ -60,7 +60,8 @@ class Stats(C.Structure):
     _fields_ = [("last_pass_ms", C.c_double), ("sum_pass_ms", C.c_double), ("passes", C.c_int64),
                 ("build_ms", C.c_double), ("upload_ms", C.c_double), ("grid_level", C.c_int32),
                 ("tree_levels", C.c_int32), ("pass_blocks", C.c_int64), ("bytes_algorithmic_per_pass", C.c_int64),
-                ("kernel_ms", C.c_double * 8), ("kernel_launches", C.c_int64 * 8), ("pass_ms_head", C.c_double * 8), ("passes_timed", C.c_int64)]
+                ("kernel_ms", C.c_double * 8), ("kernel_launches", C.c_int64 * 8), ("pass_ms_head", C.c_double * 8), ("passes_timed", C.c_int64),
+                ("loop_passes", C.c_int64), ("loop_straggler_passes", C.c_int64)]
 
 
 KERNEL_SLOTS = ["k_search_cells", "(gap)", "k_search_walk", "k_accumulate", "k_final_reduce", "single_pass_kernel", "whole_pass"]
@@ -341,8 +342,8 @@ class Engine:
             self._chk(st)
         n = max(0, min(res.iters, 64))
         return dict(status=st, iters=res.iters, diff_initial=res.diff_initial, diff_final=res.diff_final,
-                    transform=np.array(res.transform, np.float32).reshape(4, 4),
-                    diffs=np.array(res.diffs[:n], np.float32), seconds=res.seconds_total,
+                    transform=np.frombuffer(res.transform, np.float32).reshape(4, 4).copy(),      # (frombuffer: no per-element conversion)
+                    diffs=np.frombuffer(res.diffs, np.float32)[:n].copy(), seconds=res.seconds_total,
                     error=(self._L.symmicp_last_error(self._h) or b"").decode() if st != OK else "")
 
     def certificates(self):

@@ -224,6 +224,9 @@ typedef struct {
      * symmicp_begin, myicp.cpp:122), and how many passes were timed in all */
     double pass_ms_head[8];
     int64_t passes_timed;
+    /* passes that ran inside device-driven runs of iterations (symmicp_align), and those of them that carried the straggler stage
+     * (tree walk over a non-empty work list inside the run) */
+    int64_t loop_passes, loop_straggler_passes;
 } symmicp_stats;
 int symmicp_get_stats(symmicp_ctx *ctx, symmicp_stats *out);
 int symmicp_reset_stats(symmicp_ctx *ctx);

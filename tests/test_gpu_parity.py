@@ -1064,7 +1064,7 @@ def test_second_alignment_on_the_same_context(sym, oracle, cat):
     assert r2["iters"] == ro["iters"] and np.abs(r2["transform"] - ro["transform"]).max() < TOL_T
 
 
-@pytest.mark.parametrize("case", ["quirks_identity_cat", "paper_identity_cat", "paper_tree_c4", "paper_tree_threshold", "paper_tree_eps"])
+@pytest.mark.parametrize("case", ["quirks_identity_cat", "paper_identity_cat", "paper_tree_c4", "paper_tree_threshold", "paper_tree_eps", "paper_tree_stragglers"])
 def test_device_loop_matches_host_loop(sym, cat, case):
     """symmicp_align hands runs of iterations to the device (engine.cpp run_batch: solve at the end of the reduce, same source
     as the host solve -- solve_core.h -- next transform read from device memory, the loop test of myicp.cpp:123 on the device).
@@ -1077,6 +1077,12 @@ def test_device_loop_matches_host_loop(sym, cat, case):
         kw.update(mode=sym.MODE_QUIRKS, corr=sym.CORR_IDENTITY)
     elif case == "paper_identity_cat":
         kw.update(mode=sym.MODE_PAPER, corr=sym.CORR_IDENTITY, max_iters=6, fixed_iters=1)
+    elif case == "paper_tree_stragglers":
+        # a scan-like pair: its work list of far stragglers stays non-empty for a dozen passes, so the device-driven run carries the
+        # straggler stage (tree walk + accumulation of the list's pairs behind every fused pass)
+        d = synth.c5_scan(64 * 16384)
+        src, sn, tgt, tn = d["src"], d["src_n"], d["tgt"], d["tgt_n"]
+        kw.update(mode=sym.MODE_PAPER, corr=sym.CORR_TREE, max_iters=40, fixed_iters=1)
     else:
         d = synth.c4_surface(200000)
         src, sn, tgt, tn = d["src"], d["src_n"], d["tgt"], d["tgt_n"]
@@ -1107,3 +1113,6 @@ def test_device_loop_matches_host_loop(sym, cat, case):
         assert sd["passes"] == sh["passes"]
     if case == "paper_tree_c4":
         assert n == 25
+    assert sh["loop_passes"] == 0 and sd["loop_passes"] > 0
+    if case == "paper_tree_stragglers":
+        assert sd["loop_straggler_passes"] > 0, sd
