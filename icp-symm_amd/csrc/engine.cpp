@@ -1123,7 +1123,7 @@ static bool batch_eligible(const symmicp_ctx *c)
     // TREE: the fused pass is for converged alignments: under 0.4 % of the pairs searched again, a short work list at most (stragglers
     // outside the overlap: real scans always have some)
     if (c->cfg.corr == SYMMICP_CORR_TREE)
-        return !incr && c->last_list_len >= 0 && c->last_list_len <= (long long)kLoopListLimit && c->last_uncertified >= 0 &&
+        return !incr && c->last_list_len >= 0 && c->last_list_len <= (std::getenv("SYMMICP_NO_LOOP_STRAGGLERS") ? 0ll : (long long)kLoopListLimit) && c->last_uncertified >= 0 &&
                c->last_uncertified <= (long long)(loop_scan_limit(c->n_s_total) / (c->last_list_len > 0 ? 2 : 1)) && c->cert && !std::getenv("SYMMICP_NO_CERT");      // (the straggler stage costs two launches per pass)
     return false;
 }
