@@ -804,31 +804,28 @@ int symmicp_set_source(symmicp_ctx *c, const float *xyz, size_t xr, size_t xc, c
     if (tree && c->n_loc) {
         // The first pass's packets, in start order: by decreasing radius.  A packet that straddles a jump of the Morton curve takes several
         // times as many sweep steps as a compact one (median 210 us, 1 % above 830 us in the traced build), and a launch that meets such
-        // packets last ends with a handful of waves running: longest-first is the classic remedy.  Radii on the device, the sort on the
-        // host (n / 64 keys).  Measured on the 1M surface pair: 0.81 -> 0.67 ms (only the widest third first: 0.70 -- the Morton order of
-        // the rest, i.e. XCD locality, is worth less than the balance; splitting the widest packets into halves / quarters on top: no gain).
+        // packets last ends with a handful of waves running: longest-first is the classic remedy.  Radius keys, the index build's radix
+        // sort (n / 64 keys) and the table, all on the device (+0.1 ms of set_source at 1M points; a host sort cost 0.85 ms).
+        // Measured on the 1M surface pair: 0.81 -> 0.67 ms (only the widest third first: 0.70 -- the Morton order of the rest, i.e. XCD
+        // locality, is worth less than the balance; splitting the widest packets into halves / quarters on top: no gain).
         const uint32_t nblk = (c->n_loc + 63u) / 64u;
         static const bool ordered = !(std::getenv("SYMMICP_PACKET_ORDER") && std::getenv("SYMMICP_PACKET_ORDER")[0] == '0');      // A/B runs
         c->pkt_tab = nullptr; c->pkt_count = 0;
         if (ordered) {
-            DevBuf<float> r2;
-            HIP_TRY(c, r2.alloc_temp(c->arena, nblk));
-            launch_packet_radius(c->src0, c->n_loc, r2.p, c->stream);
-            std::vector<float> h(nblk);
-            HIP_TRY(c, hipMemcpyAsync(h.data(), r2.p, sizeof(float) * nblk, hipMemcpyDeviceToHost, c->stream));
-            HIP_TRY(c, hipStreamSynchronize(c->stream));
-            std::vector<uint32_t> order(nblk);
-            for (uint32_t k = 0; k < nblk; k++) order[k] = k;
-            std::sort(order.begin(), order.end(), [&](uint32_t u, uint32_t v) { return h[u] != h[v] ? h[u] > h[v] : u < v; });
-            std::vector<uint32_t> flat((size_t)nblk * 2);
-            for (uint32_t k = 0; k < nblk; k++) {
-                const uint32_t first = order[k] * 64u, left = c->n_loc - first;
-                flat[2 * (size_t)k] = first; flat[2 * (size_t)k + 1] = left < 64u ? left : 64u;
-            }
+            DevBuf<uint32_t> keys, vals, kt, vt, ws;
+            const size_t wse = radix_sort_ws_elems(nblk);
+            HIP_TRY(c, keys.alloc_temp(c->arena, nblk));
+            HIP_TRY(c, vals.alloc_temp(c->arena, nblk));
+            HIP_TRY(c, kt.alloc_temp(c->arena, nblk));
+            HIP_TRY(c, vt.alloc_temp(c->arena, nblk));
+            HIP_TRY(c, ws.alloc_temp(c->arena, wse));
+            static const int key_bits = std::getenv("SYMMICP_PACKET_KEY_BITS") ? std::atoi(std::getenv("SYMMICP_PACKET_KEY_BITS")) : 32;      // (16 / 24-bit keys: first pass 0.68 ms against 0.66)
+            launch_packet_radius(c->src0, c->n_loc, keys.p, vals.p, key_bits, c->stream);
+            radix_sort_pairs(keys.p, vals.p, kt.p, vt.p, nblk, key_bits, ws.p, wse, c->stream);
             c->pkt_tab = reinterpret_cast<uint32_t *>(c->src_all + o_pkt);
             c->pkt_count = nblk;
-            HIP_TRY(c, hipMemcpyAsync(c->pkt_tab, flat.data(), sizeof(uint32_t) * flat.size(), hipMemcpyHostToDevice, c->stream));
-            HIP_TRY(c, hipStreamSynchronize(c->stream));       // (`flat` is about to go out of scope)
+            launch_packet_table(vals.p, nblk, c->n_loc, reinterpret_cast<uint2 *>(c->pkt_tab), c->stream);
+            HIP_TRY(c, hipStreamSynchronize(c->stream));       // (the temporaries are about to go out of scope)
         }
     }
     HIP_TRY(c, hipStreamSynchronize(c->stream));       // (the arena-backed upload is read by the gather above)

@@ -506,8 +506,8 @@ __global__ __launch_bounds__(64, PKT_WAVES) void k_search_packet(PassArgs a, Tar
 
 // Predicted cost of a packet: the radius of its 64 queries around their centroid (invariant under the rigid transform the
 // alignment applies).  Packets that straddle a jump of the Morton curve are several times wider than the rest and take several times
-// as many sweep steps; the host starts the packets longest-first (engine.cpp, set_source).
-__global__ __launch_bounds__(64) void k_packet_radius(CloudSoA src, uint32_t n, float *__restrict__ radius2)
+// as many sweep steps; the packets are started longest-first (engine.cpp, set_source: radius keys, the radix sort of the index build, table).
+__global__ __launch_bounds__(64) void k_packet_radius(CloudSoA src, uint32_t n, uint32_t *__restrict__ keys, uint32_t *__restrict__ vals, int key_bits)
 {
     const uint32_t i = blockIdx.x * 64u + threadIdx.x;
     const bool active = i < n;
@@ -521,13 +521,32 @@ __global__ __launch_bounds__(64) void k_packet_radius(CloudSoA src, uint32_t n, 
     float r2 = active ? dist2(x, y, z, cx, cy, cz) : 0.f;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) r2 = fmaxf(r2, __shfl_xor(r2, off, 64));
-    if (threadIdx.x == 0) radius2[blockIdx.x] = r2;
+    if (threadIdx.x == 0) {
+        // sort key: descending squared radius, its top key_bits bits (16: sign, exponent, 7 bits of mantissa; NaN / negative cannot occur, a
+        // non-finite radius sorts first); packets of (nearly) the same radius keep their Morton order (the sort is stable)
+        keys[blockIdx.x] = key_bits >= 32 ? ~__float_as_uint(r2) : ((1u << key_bits) - 1u) - (__float_as_uint(r2) >> (32 - key_bits));
+        vals[blockIdx.x] = blockIdx.x;
+    }
 }
 
-void launch_packet_radius(const CloudSoA &src, uint32_t n, float *radius2, hipStream_t s)
+// the packet table in start order: (first query, count)
+__global__ __launch_bounds__(256) void k_packet_table(const uint32_t *__restrict__ order, uint32_t nblk, uint32_t n, uint2 *__restrict__ tab)
+{
+    const uint32_t k = blockIdx.x * 256u + threadIdx.x;
+    if (k >= nblk) return;
+    const uint32_t first = order[k] * 64u;
+    tab[k] = make_uint2(first, min(64u, n - first));
+}
+
+void launch_packet_radius(const CloudSoA &src, uint32_t n, uint32_t *keys, uint32_t *vals, int key_bits, hipStream_t s)
 {
     const uint32_t npk = (n + 63u) / 64u;
-    if (npk) hipLaunchKernelGGL(k_packet_radius, dim3(npk), dim3(64), 0, s, src, n, radius2);
+    if (npk) hipLaunchKernelGGL(k_packet_radius, dim3(npk), dim3(64), 0, s, src, n, keys, vals, key_bits);
+}
+
+void launch_packet_table(const uint32_t *order, uint32_t nblk, uint32_t n, uint2 *tab, hipStream_t s)
+{
+    if (nblk) hipLaunchKernelGGL(k_packet_table, dim3((nblk + 255u) / 256u), dim3(256), 0, s, order, nblk, n, tab);
 }
 
 // first pass of an alignment: no previous pairs, every query is searched -- packets over the whole (sorted) share
