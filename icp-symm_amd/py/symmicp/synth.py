@@ -63,6 +63,26 @@ def shuffle_perm(seed, n):
     return np.argsort(splitmix64(seed, n, 7), kind="stable")
 
 
+def _spread10(v):
+    v = v.astype(np.uint64) & np.uint64(0x3FF)
+    v = (v | (v << np.uint64(16))) & np.uint64(0x030000FF)
+    v = (v | (v << np.uint64(8))) & np.uint64(0x0300F00F)
+    v = (v | (v << np.uint64(4))) & np.uint64(0x030C30C3)
+    v = (v | (v << np.uint64(2))) & np.uint64(0x09249249)
+    return v
+
+
+def sweep_order(xyz):
+    """Row permutation that puts a cloud in a spatially coherent order (30-bit Morton curve over its bounding box, stable): what a
+    scanner's sweep gives for free and what contiguous row ranges need to be compact shares in a multi-GPU run."""
+    p = np.asarray(xyz, np.float64)
+    lo = p.min(0)
+    ext = max(float((p.max(0) - lo).max()), 1e-30) * 1.00001
+    q = np.minimum(((p - lo) / ext * 1024.0).astype(np.int64), 1023)
+    key = (_spread10(q[:, 2]) << np.uint64(2)) | (_spread10(q[:, 1]) << np.uint64(1)) | _spread10(q[:, 0])
+    return np.argsort(key, kind="stable")
+
+
 def c3_uniform(n=100_000, seed=0xC3):
     src = np.stack([uniform01(seed, n, 0), uniform01(seed, n, 1), uniform01(seed, n, 2)], 1)
     nrm = _unit_sphere(seed, n, 3)

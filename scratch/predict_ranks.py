@@ -1,6 +1,6 @@
 """Per-rank kernel time of an N-way sharded alignment, measured on ONE GPU: N contexts in external-exchange mode run
 one after the other, the script plays the all-reduce.  max over ranks of the per-pass kernel time is what a real N-GPU
-run would spend in kernels (exchange and host turn-around not included).  python predict_ranks.py c4|c5 points N iters"""
+run would spend in kernels (exchange and host turn-around not included).  python predict_ranks.py c4|c5 points N iters [sweep]"""
 import os, sys, time
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 sys.path.insert(0, os.path.join(ROOT, "icp-symm_amd", "py"))
@@ -8,6 +8,8 @@ import numpy as np, symmicp as sym
 from symmicp import synth
 kind, n, world, iters = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
 d = {"c4": synth.c4_surface, "c5": synth.c5_scan}[kind](n)
+if len(sys.argv) > 5 and sys.argv[5] == "sweep":          # source rows in a spatially coherent order: contiguous row ranges are compact shares
+    o = synth.sweep_order(d["src"]); d["src"], d["src_n"] = d["src"][o], d["src_n"][o]
 engs = []
 for r in range(world):
     e = sym.Engine(mode=sym.MODE_PAPER, corr=sym.CORR_TREE, max_iters=iters, fixed_iters=1)

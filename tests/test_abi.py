@@ -203,3 +203,16 @@ int main(void) {
     import torch
     if not torch.cuda.is_available():
         assert "create_status" in r.stdout and "ctx null" in r.stdout and "create_status 0" not in r.stdout
+
+
+def test_sweep_order_is_a_coherent_permutation():
+    """synth.sweep_order (bench.py, N > 1): a permutation of the rows after which contiguous row ranges are spatially compact"""
+    import numpy as np
+    from symmicp import synth
+    d = synth.c4_surface(20000)
+    o = synth.sweep_order(d["src"])
+    assert np.array_equal(np.sort(o), np.arange(20000))
+    p = d["src"][o].astype(np.float64)
+    def spread(q):          # mean bounding-box diagonal of 8 contiguous row ranges
+        return np.mean([np.linalg.norm(q[k * 2500:(k + 1) * 2500].max(0) - q[k * 2500:(k + 1) * 2500].min(0)) for k in range(8)])
+    assert spread(p) < 0.6 * spread(d["src"].astype(np.float64))
