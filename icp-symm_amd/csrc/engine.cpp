@@ -708,11 +708,11 @@ int symmicp_set_target(symmicp_ctx *c, const float *xyz, size_t xr, size_t xc, c
         HIP_TRY(c, hipMalloc((void **)&c->dbg, 12 * sizeof(unsigned long long)));
         HIP_TRY(c, hipMemset(c->dbg, 0, 12 * sizeof(unsigned long long)));
         c->ix.dbg = c->dbg;
-        if (std::getenv("SYMMICP_DEBUG_TRACE")) {
-            HIP_TRY(c, hipMalloc((void **)&c->dbg_trace, ((size_t)1 << 21) * 16));
-            HIP_TRY(c, hipMemset(c->dbg_trace, 0, ((size_t)1 << 21) * 16));
-            c->ix.dbg_trace = c->dbg_trace;
-        }
+    }
+    if (std::getenv("SYMMICP_DEBUG_TRACE")) {          // (alone: the production kernel with a timing-only trace)
+        HIP_TRY(c, hipMalloc((void **)&c->dbg_trace, ((size_t)1 << 21) * 16));
+        HIP_TRY(c, hipMemset(c->dbg_trace, 0, ((size_t)1 << 21) * 16));
+        c->ix.dbg_trace = c->dbg_trace;
     }
     c->have_index = true;
     c->st.build_ms = (now_s() - t1) * 1e3;
@@ -1061,6 +1061,15 @@ static int run_pass(symmicp_ctx *c, const float Xapply[16], bool from_cur, bool 
     }
     if (ev) c->ev_used++;
     c->t_last_done = now_s(); c->n_pass_timed++;
+    if (!c->ix.dbg && c->dbg_trace && first) {
+        if (FILE *f = std::fopen(std::getenv("SYMMICP_DEBUG_TRACE"), "wb")) {
+            std::vector<unsigned long long> t(((size_t)1 << 21) * 2);
+            hipMemcpy(t.data(), c->dbg_trace, t.size() * 8, hipMemcpyDeviceToHost);
+            std::fwrite(t.data(), 8, t.size(), f);
+            std::fclose(f);
+        }
+        hipMemset(c->dbg_trace, 0, ((size_t)1 << 21) * 16);
+    }
     if (c->ix.dbg) {
         unsigned long long h[12];
         hipMemcpy(h, c->ix.dbg, sizeof(h), hipMemcpyDeviceToHost);

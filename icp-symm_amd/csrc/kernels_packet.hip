@@ -276,8 +276,8 @@ __device__ __noinline__ void pkt_dfs(const float4 *__restrict__ onodes, const fl
 // there too (previous pair as the bound, certificate test per lane) and lose to the cell scans of k_search_cells: 0.55 ms
 // against 0.35 ms for pass 2 of the 1M-point surface pair, 0.56 against 0.17 for pass 3 -- with tight bounds a packet is ten
 // nearly empty levels of round trips.
-constexpr int kFrontCap = 512;            // frontier nodes per level (two buffers of uint32 in LDS = the DFS stack's 4 KB)
-static_assert(2 * kFrontCap * sizeof(uint32_t) == kPktStack * 2 * sizeof(float4), "frontier buffers alias the DFS stack");
+constexpr int kFrontCap = 512;            // frontier nodes per level (two buffers of uint32 in LDS = the DFS stack's 4 KB); 256 / 384: 1.08 ms (more packets fall back to the depth-first walk), 1024: 0.90 ms (the widest packets sweep 1000-node levels: slower than falling back) against 0.66
+static_assert(2 * kFrontCap * sizeof(uint32_t) <= kPktStack * 2 * sizeof(float4), "frontier buffers alias the DFS stack");
 
 #ifndef PKT_WAVES
 #define PKT_WAVES 4
@@ -306,7 +306,7 @@ __global__ __launch_bounds__(64, PKT_WAVES) void k_search_packet(PassArgs a, Tar
         if (a.pkt_tab) { const uint2 e = a.pkt_tab[slot]; first = e.x; count = e.y; }
         const uint32_t pk = slot;
         unsigned long long t_start = 0;
-        if (DBG) t_start = __builtin_amdgcn_s_memrealtime();
+        if (DBG || ix.dbg_trace) t_start = __builtin_amdgcn_s_memrealtime();
         const uint32_t i = first + (uint32_t)lane;
         const bool active = (uint32_t)lane < count && i < a.n;
         float px = 0.f, py = 0.f, pz = 0.f;
@@ -483,6 +483,12 @@ __global__ __launch_bounds__(64, PKT_WAVES) void k_search_packet(PassArgs a, Tar
             a.cert[i] = make_float4(px, py, pz, L);
             if (b.pos >= 0) store_pair_record(a, ix, i, b.pos);
             else a.pairrec[2 * (size_t)i + 1] = make_float4(0.f, 0.f, 0.f, 1.f);
+        }
+        if (!DBG && ix.dbg_trace && lane == 0 && (size_t)pk < ((size_t)1 << 21)) {
+            // timing-only trace of the production kernel (SYMMICP_DEBUG_TRACE without SYMMICP_DEBUG_COUNTERS): two stores per packet
+            const unsigned long long dt = __builtin_amdgcn_s_memrealtime() - t_start;
+            ix.dbg_trace[2 * (size_t)pk] = t_start;
+            ix.dbg_trace[2 * (size_t)pk + 1] = (dt << 32) | (unsigned long long)(ovf_pk ? 1u : 0u);
         }
         if (DBG && lane == 0) {
             const unsigned long long dt = __builtin_amdgcn_s_memrealtime() - t_start;      // 100 MHz ticks
