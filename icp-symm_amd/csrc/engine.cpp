@@ -736,7 +736,7 @@ int symmicp_set_source(symmicp_ctx *c, const float *xyz, size_t xr, size_t xc, c
     symmicp_shard_range(n, c->nranks, c->rank, &b0, &bc);
     const size_t nu = bc > 0 ? bc : 1;                       // rows uploaded (an empty share still stages one row)
     const size_t r0 = bc > 0 ? b0 : 0;
-    arena_begin(c->arena, nu * (48 + 4 * (xr + nr)) + ((size_t)1 << 20));
+    arena_begin(c->arena, nu * (52 + 4 * (xr + nr)) + ((size_t)1 << 20));      // (+4 B per point: the packet table's temporaries)
     DevBuf<float> full;
     int st = upload_planar(c, xyz + r0 * xr, xr, xc, nrm + r0 * nr, nr, nc, nu, full, /*temp=*/true, nullptr);
     if (st != SYMMICP_OK) return st;
@@ -756,7 +756,7 @@ int symmicp_set_source(symmicp_ctx *c, const float *xyz, size_t xr, size_t xc, c
     const size_t o_best = brute ? take(sizeof(unsigned long long) * nl) : 0;
     const size_t o_cert = tree ? take(sizeof(float) * 4 * nl) : 0;
     const size_t o_certk = tree ? take(sizeof(uint32_t) * 8 * nl) : 0, o_hoodr = tree ? take(sizeof(float) * 2 * nl) : 0;
-    const size_t o_pkt = tree ? take(sizeof(uint32_t) * 2 * ((nl + 63) / 64)) : 0;
+    const size_t o_pkt = tree ? take(sizeof(uint32_t) * 2 * 4 * ((nl + 63) / 64)) : 0;        // (a block of 64 queries may be cut into 4 packets)
     const size_t o_prec = tree ? take(sizeof(float4) * 2 * nl) : 0;
     const size_t o_wl = tree ? take(sizeof(uint32_t) * 2 * per_list) : 0, o_cnt = tree ? take(sizeof(uint32_t) * 2 * ncount) : 0;      // work + retry lists
     if (off > c->src_all_cap) {
@@ -812,19 +812,30 @@ int symmicp_set_source(symmicp_ctx *c, const float *xyz, size_t xr, size_t xc, c
         static const bool ordered = !(std::getenv("SYMMICP_PACKET_ORDER") && std::getenv("SYMMICP_PACKET_ORDER")[0] == '0');      // A/B runs
         c->pkt_tab = nullptr; c->pkt_count = 0;
         if (ordered) {
-            DevBuf<uint32_t> keys, vals, kt, vt, ws;
-            const size_t wse = radix_sort_ws_elems(nblk);
-            HIP_TRY(c, keys.alloc_temp(c->arena, nblk));
-            HIP_TRY(c, vals.alloc_temp(c->arena, nblk));
-            HIP_TRY(c, kt.alloc_temp(c->arena, nblk));
-            HIP_TRY(c, vt.alloc_temp(c->arena, nblk));
-            HIP_TRY(c, ws.alloc_temp(c->arena, wse));
+            // (a block of 64 queries is cut into runs at its jumps of the Morton curve: k_packet_runs)
+            static const float jump = std::getenv("SYMMICP_PACKET_JUMP") ? (float)std::atof(std::getenv("SYMMICP_PACKET_JUMP")) : -1.0f;      // x the block's scale; 0: never cut
             static const int key_bits = std::getenv("SYMMICP_PACKET_KEY_BITS") ? std::atoi(std::getenv("SYMMICP_PACKET_KEY_BITS")) : 32;      // (16 / 24-bit keys: first pass 0.68 ms against 0.66)
-            launch_packet_radius(c->src0, c->n_loc, keys.p, vals.p, key_bits, c->stream);
-            radix_sort_pairs(keys.p, vals.p, kt.p, vt.p, nblk, key_bits, ws.p, wse, c->stream);
+            const uint32_t cap = 4u * nblk;
+            DevBuf<uint32_t> keys, vals, kt, vt, ws, cnt;
+            DevBuf<uint2> runs;
+            const size_t wse = radix_sort_ws_elems(cap);
+            HIP_TRY(c, keys.alloc_temp(c->arena, cap));
+            HIP_TRY(c, vals.alloc_temp(c->arena, cap));
+            HIP_TRY(c, kt.alloc_temp(c->arena, cap));
+            HIP_TRY(c, vt.alloc_temp(c->arena, cap));
+            HIP_TRY(c, runs.alloc_temp(c->arena, cap));
+            HIP_TRY(c, ws.alloc_temp(c->arena, wse));
+            HIP_TRY(c, cnt.alloc_temp(c->arena, 1));
+            HIP_TRY(c, hipMemsetAsync(cnt.p, 0, sizeof(uint32_t), c->stream));
+            launch_packet_runs(c->src0, c->n_loc, jump, runs.p, keys.p, vals.p, cnt.p, key_bits, c->stream);
+            uint32_t npk = 0;
+            HIP_TRY(c, hipMemcpyAsync(&npk, cnt.p, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            if (npk < nblk || npk > cap) { forget_source(c); return fail(c, SYMMICP_ERR_HIP, "packet table: count out of range"); }
+            radix_sort_pairs(keys.p, vals.p, kt.p, vt.p, npk, key_bits, ws.p, wse, c->stream);
             c->pkt_tab = reinterpret_cast<uint32_t *>(c->src_all + o_pkt);
-            c->pkt_count = nblk;
-            launch_packet_table(vals.p, nblk, c->n_loc, reinterpret_cast<uint2 *>(c->pkt_tab), c->stream);
+            c->pkt_count = npk;
+            launch_packet_table(vals.p, runs.p, npk, reinterpret_cast<uint2 *>(c->pkt_tab), c->stream);
             HIP_TRY(c, hipStreamSynchronize(c->stream));       // (the temporaries are about to go out of scope)
         }
     }

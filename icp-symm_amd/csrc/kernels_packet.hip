@@ -510,49 +510,89 @@ __global__ __launch_bounds__(64, PKT_WAVES) void k_search_packet(PassArgs a, Tar
     }
 }
 
-// Predicted cost of a packet: the radius of its 64 queries around their centroid (invariant under the rigid transform the
-// alignment applies).  Packets that straddle a jump of the Morton curve are several times wider than the rest and take several times
-// as many sweep steps; the packets are started longest-first (engine.cpp, set_source: radius keys, the radix sort of the index build, table).
-__global__ __launch_bounds__(64) void k_packet_radius(CloudSoA src, uint32_t n, uint32_t *__restrict__ keys, uint32_t *__restrict__ vals, int key_bits)
+// The first pass's packets and their start order (engine.cpp, set_source).  A packet is a run of up to 64 consecutive queries of the
+// Morton-sorted share.  Its cost is predicted by the radius of its queries around their centroid (invariant under the rigid transform
+// the alignment applies): packets are started longest-first.  A block of 64 queries that straddles a jump of the Morton curve would be
+// one packet 6-20 times wider than the rest -- 100-190 sweep steps instead of 19, 300-600 us: the slowest packets of every launch, and
+// what a launch with few packets per GPU (a rank's share) lasts as long as -- so a block is cut into runs at its (up to 3) jumps: steps
+// between consecutive queries longer than kJumpFactor x the block's own scale (the smallest radius of its four groups of 16).
+// Per run: (first, count) into `runs`, key = descending squared radius (top key_bits bits), value = its index in `runs`.
+constexpr float kJumpFactor = 5.0f;        // (3: 0.60 ms, 5: 0.55, 6: 0.56, 8-10: 0.59, never: 0.655 on the 1M surface pair)
+constexpr int kMaxRunsPerBlock = 4;
+
+__global__ __launch_bounds__(64) void k_packet_runs(CloudSoA src, uint32_t n, float jump_factor, uint2 *__restrict__ runs, uint32_t *__restrict__ keys,
+                                                    uint32_t *__restrict__ vals, uint32_t *__restrict__ count, int key_bits)
 {
     const uint32_t i = blockIdx.x * 64u + threadIdx.x;
+    const int lane = threadIdx.x;
     const bool active = i < n;
     const float x = active ? src.x[i] : 0.f, y = active ? src.y[i] : 0.f, z = active ? src.z[i] : 0.f;
+    // scale of the block: smallest squared radius of its (non-empty) groups of 16
     float sx = x, sy = y, sz = z, cnt = active ? 1.f : 0.f;
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
+    for (int off = 1; off < 16; off <<= 1) {
         sx += __shfl_xor(sx, off, 64); sy += __shfl_xor(sy, off, 64); sz += __shfl_xor(sz, off, 64); cnt += __shfl_xor(cnt, off, 64);
     }
-    const float cx = sx / cnt, cy = sy / cnt, cz = sz / cnt;
-    float r2 = active ? dist2(x, y, z, cx, cy, cz) : 0.f;
+    float r16 = active ? dist2(x, y, z, sx / cnt, sy / cnt, sz / cnt) : 0.f;
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) r2 = fmaxf(r2, __shfl_xor(r2, off, 64));
-    if (threadIdx.x == 0) {
-        // sort key: descending squared radius, its top key_bits bits (16: sign, exponent, 7 bits of mantissa; NaN / negative cannot occur, a
-        // non-finite radius sorts first); packets of (nearly) the same radius keep their Morton order (the sort is stable)
-        keys[blockIdx.x] = key_bits >= 32 ? ~__float_as_uint(r2) : ((1u << key_bits) - 1u) - (__float_as_uint(r2) >> (32 - key_bits));
-        vals[blockIdx.x] = blockIdx.x;
+    for (int off = 1; off < 16; off <<= 1) r16 = fmaxf(r16, __shfl_xor(r16, off, 64));
+    float scale2 = (cnt >= 8.f) ? r16 : __int_as_float(0x7f800000);        // (a nearly empty tail group says nothing)
+    scale2 = fminf(scale2, __shfl_xor(scale2, 16, 64));
+    scale2 = fminf(scale2, __shfl_xor(scale2, 32, 64));
+    // jumps: steps from the previous query of the block longer than the factor allows
+    const float px = __shfl_up(x, 1, 64), py = __shfl_up(y, 1, 64), pz = __shfl_up(z, 1, 64);
+    bool jump = active && lane > 0 && jump_factor > 0.f && dist2(x, y, z, px, py, pz) > jump_factor * jump_factor * scale2;
+    unsigned long long jm = __ballot(jump);
+    // keep the first kMaxRunsPerBlock - 1 jumps
+    for (int k = 0; k < kMaxRunsPerBlock - 1 && jm; k++) jm &= jm - 1;       // jm: the jumps beyond the limit ...
+    const unsigned long long cuts = (__ballot(jump) & ~jm) | 1ull;            // ... removed; bit j set: a run starts at lane j
+    const unsigned long long act = __ballot(active);
+    // this lane's run: from the last cut at or below it to the next cut (or the end of the active lanes)
+    const unsigned long long below = cuts & ((2ull << lane) - 1ull);
+    const int start = 63 - __clzll((long long)below);
+    const unsigned long long above = cuts & ~((2ull << lane) - 1ull);
+    const int nact = __popcll(act);
+    const int end = above ? (int)__ffsll((long long)above) - 1 : nact;       // exclusive
+    // radius of the run: centroid, then the farthest member (segmented by run: lanes exchange only within [start, end))
+    float cx = 0.f, cy = 0.f, cz = 0.f, r2 = 0.f;
+    for (unsigned long long m = cuts; m; m &= m - 1) {                       // (<= 4 runs)
+        const int s0 = (int)__ffsll((long long)m) - 1;
+        const bool mine = active && start == s0;
+        float ax = mine ? x : 0.f, ay = mine ? y : 0.f, az = mine ? z : 0.f, ac = mine ? 1.f : 0.f;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            ax += __shfl_xor(ax, off, 64); ay += __shfl_xor(ay, off, 64); az += __shfl_xor(az, off, 64); ac += __shfl_xor(ac, off, 64);
+        }
+        float d = mine ? dist2(x, y, z, ax / ac, ay / ac, az / ac) : 0.f;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) d = fmaxf(d, __shfl_xor(d, off, 64));
+        if (mine) { cx = ax; cy = ay; cz = az; r2 = d; }
+    }
+    (void)cx; (void)cy; (void)cz;
+    if (active && lane == start) {
+        const uint32_t k = atomicAdd(count, 1u);
+        runs[k] = make_uint2(i, (uint32_t)(end - start));
+        keys[k] = key_bits >= 32 ? ~__float_as_uint(r2) : ((1u << key_bits) - 1u) - (__float_as_uint(r2) >> (32 - key_bits));
+        vals[k] = k;
     }
 }
 
-// the packet table in start order: (first query, count)
-__global__ __launch_bounds__(256) void k_packet_table(const uint32_t *__restrict__ order, uint32_t nblk, uint32_t n, uint2 *__restrict__ tab)
+// the packet table in start order
+__global__ __launch_bounds__(256) void k_packet_table(const uint32_t *__restrict__ order, const uint2 *__restrict__ runs, uint32_t npk, uint2 *__restrict__ tab)
 {
     const uint32_t k = blockIdx.x * 256u + threadIdx.x;
-    if (k >= nblk) return;
-    const uint32_t first = order[k] * 64u;
-    tab[k] = make_uint2(first, min(64u, n - first));
+    if (k < npk) tab[k] = runs[order[k]];
 }
 
-void launch_packet_radius(const CloudSoA &src, uint32_t n, uint32_t *keys, uint32_t *vals, int key_bits, hipStream_t s)
+void launch_packet_runs(const CloudSoA &src, uint32_t n, float jump_factor, uint2 *runs, uint32_t *keys, uint32_t *vals, uint32_t *count, int key_bits, hipStream_t s)
 {
-    const uint32_t npk = (n + 63u) / 64u;
-    if (npk) hipLaunchKernelGGL(k_packet_radius, dim3(npk), dim3(64), 0, s, src, n, keys, vals, key_bits);
+    const uint32_t nblk = (n + 63u) / 64u;
+    if (nblk) hipLaunchKernelGGL(k_packet_runs, dim3(nblk), dim3(64), 0, s, src, n, jump_factor < 0.f ? kJumpFactor : jump_factor, runs, keys, vals, count, key_bits);
 }
 
-void launch_packet_table(const uint32_t *order, uint32_t nblk, uint32_t n, uint2 *tab, hipStream_t s)
+void launch_packet_table(const uint32_t *order, const uint2 *runs, uint32_t npk, uint2 *tab, hipStream_t s)
 {
-    if (nblk) hipLaunchKernelGGL(k_packet_table, dim3((nblk + 255u) / 256u), dim3(256), 0, s, order, nblk, n, tab);
+    if (npk) hipLaunchKernelGGL(k_packet_table, dim3((npk + 255u) / 256u), dim3(256), 0, s, order, runs, npk, tab);
 }
 
 // first pass of an alignment: no previous pairs, every query is searched -- packets over the whole (sorted) share

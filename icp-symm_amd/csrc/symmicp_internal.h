@@ -189,8 +189,9 @@ void launch_gather_f4(const float *x, const float *y, const float *z, const floa
                       const uint32_t *order, uint32_t n, float4 *tq, float4 *tn, hipStream_t s);
 void launch_gather_soa(const CloudSoA &src, const uint32_t *order, uint32_t n, CloudSoA dst, hipStream_t s);
 void launch_offset_u32(const uint32_t *in, uint32_t off, uint32_t n, uint32_t *out, hipStream_t s);
-void launch_packet_radius(const CloudSoA &src, uint32_t n, uint32_t *keys, uint32_t *vals, int key_bits, hipStream_t s);
-void launch_packet_table(const uint32_t *order, uint32_t nblk, uint32_t n, uint2 *tab, hipStream_t s);
+// first pass: the packets (runs of <= 64 queries, blocks cut at jumps of the Morton curve; jump_factor < 0: the default) with radius keys, and the table in start order
+void launch_packet_runs(const CloudSoA &src, uint32_t n, float jump_factor, uint2 *runs, uint32_t *keys, uint32_t *vals, uint32_t *count, int key_bits, hipStream_t s);
+void launch_packet_table(const uint32_t *order, const uint2 *runs, uint32_t npk, uint2 *tab, hipStream_t s);
 void launch_deinterleave3(const float *raw, size_t row_stride, size_t offset, uint32_t n, float *x, float *y, float *z, hipStream_t s);
 void launch_level_hist(const uint32_t *keys, uint32_t n, uint32_t *hist16, hipStream_t s);
 void launch_cell_table(const uint32_t *keys, uint32_t n, int glevel, const uint32_t *nid_top, uint32_t *ctop, uint2 *cells, hipStream_t s);
