@@ -488,7 +488,7 @@ __global__ __launch_bounds__(64, PKT_WAVES) void k_search_packet(PassArgs a, Tar
             // timing-only trace of the production kernel (SYMMICP_DEBUG_TRACE without SYMMICP_DEBUG_COUNTERS): two stores per packet
             const unsigned long long dt = __builtin_amdgcn_s_memrealtime() - t_start;
             ix.dbg_trace[2 * (size_t)pk] = t_start;
-            ix.dbg_trace[2 * (size_t)pk + 1] = (dt << 32) | (unsigned long long)(ovf_pk ? 1u : 0u);
+            ix.dbg_trace[2 * (size_t)pk + 1] = (dt << 32) | (unsigned long long)((first << 1) | (ovf_pk ? 1u : 0u));      // (first query, fallback flag)
         }
         if (DBG && lane == 0) {
             const unsigned long long dt = __builtin_amdgcn_s_memrealtime() - t_start;      // 100 MHz ticks

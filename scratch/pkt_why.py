@@ -1,5 +1,5 @@
-"""What makes a packet slow: release-kernel packet durations (SYMMICP_DEBUG_TRACE) against the geometry of the packet's queries.
-SYMMICP_DEBUG_TRACE=/tmp/t.bin SYMMICP_PACKET_ORDER=0 python scratch/pkt_why.py   (packets in Morton order: slot = block of 64 rows)"""
+"""What makes a packet slow: production-kernel packet durations (SYMMICP_DEBUG_TRACE alone) against the geometry of the packet's queries.
+SYMMICP_DEBUG_TRACE=/tmp/t.bin python scratch/pkt_why.py   (the trace carries each packet's first query; the source is given in its sorted order)"""
 import os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "icp-symm_amd", "py"))
 import numpy as np, symmicp
@@ -12,18 +12,21 @@ if __name__ == "__main__":
         e.set_target(d["tgt"], d["tgt_n"]); e.set_source(src, sn)
         e.begin(); e.begin()
     t = np.fromfile(os.environ["SYMMICP_DEBUG_TRACE"], dtype=np.uint64).reshape(-1, 2)
-    n = len(src) // 64
-    dur = (t[:n, 1] >> np.uint64(32)).astype(np.float64) * 0.01          # us
-    ovf = (t[:n, 1] & np.uint64(1)).astype(bool)
+    t = t[t[:, 0] != 0]
+    dur = (t[:, 1] >> np.uint64(32)).astype(np.float64) * 0.01          # us
+    first = ((t[:, 1] & np.uint64(0xFFFFFFFF)) >> np.uint64(1)).astype(np.int64)
+    order = np.argsort(first); first, dur, slot = first[order], dur[order], order
+    count = np.minimum(np.diff(np.append(first, len(src))), 64)
     tree = cKDTree(d["tgt"].astype(np.float64))
-    d1 = tree.query(src.astype(np.float64), k=1)[0][: n * 64].reshape(n, 64)
-    g = src[: n * 64].reshape(n, 64, 3).astype(np.float64)
-    rad = np.sqrt(((g - g.mean(1, keepdims=True)) ** 2).sum(2).max(1))
-    feats = dict(radius=rad, d1_mean=d1.mean(1), d1_max=d1.max(1), d1_spread=d1.max(1) - d1.min(1), rad_plus_d1=rad + d1.max(1))
-    print("packets %d, duration mean %.0f us, max %.0f us, fallback %d" % (n, dur.mean(), dur.max(), ovf.sum()))
+    d1_all = tree.query(src.astype(np.float64), k=1)[0]
+    rad = np.empty(len(first)); d1m = np.empty(len(first)); d1x = np.empty(len(first))
+    for k, (f, c) in enumerate(zip(first, count)):
+        g = src[f:f + c].astype(np.float64)
+        rad[k] = np.sqrt(((g - g.mean(0)) ** 2).sum(1).max()); d1m[k] = d1_all[f:f + c].mean(); d1x[k] = d1_all[f:f + c].max()
+    feats = dict(count=count.astype(np.float64), radius=rad, d1_mean=d1m, d1_max=d1x, rad_plus_d1=rad + d1x, slot=slot.astype(np.float64))
+    print("packets %d, duration mean %.0f us, max %.0f us; counts: %s" % (len(first), dur.mean(), dur.max(), np.bincount(np.minimum(count // 16, 4))))
     for k, v in feats.items():
-        print("  corr(duration, %s) = %.3f   (log-log %.3f)" % (k, np.corrcoef(dur, v)[0, 1], np.corrcoef(np.log(dur + 1), np.log(v + 1e-9))[0, 1]))
-    top = np.argsort(-dur)[:15]
+        print("  corr(duration, %s) = %.3f" % (k, np.corrcoef(dur, v)[0, 1]))
     med = {k: np.median(v) for k, v in feats.items()}
-    for p in top:
-        print("  packet %6d: %4.0f us%s  " % (p, dur[p], "*" if ovf[p] else " ") + "  ".join("%s %.1fx" % (k, v[p] / med[k]) for k, v in feats.items()))
+    for p in np.argsort(-dur)[:15]:
+        print("  first %7d: %4.0f us  " % (first[p], dur[p]) + "  ".join(("%s %.0f" % (k, v[p])) if k in ("count", "slot") else ("%s %.1fx" % (k, v[p] / med[k])) for k, v in feats.items()))
