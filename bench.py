@@ -193,7 +193,10 @@ def main():
     # ---- timed: begin + exactly K steps, barrier + sync on both sides, max over ranks --------------
     # two HIP events bracket every pass inside the timed region (engine stream): the pass durations the roofline uses
     no_events = bool(os.environ.get("SYMMICP_BENCH_NO_EVENTS"))
-    eng.enable_timing(0 if no_events else 1)
+    # (mode 3: every pass of the host loop, every 4th pass of a device-driven run -- an event record costs ~2.5 us of GPU timeline, and two
+    # per pass made the timed region 7 % slower than the same alignment without events; SYMMICP_BENCH_ALL_EVENTS=1: every pass)
+    all_events = bool(os.environ.get("SYMMICP_BENCH_ALL_EVENTS"))
+    eng.enable_timing(0 if no_events else (1 if all_events else 3))
     best = None
     for _ in range(max(1, args.repeats)):
         eng.reset_stats()
@@ -228,16 +231,21 @@ def main():
     # ---- per-pass durations of the timed region -----------------------------------------------------
     np_timed = int(st_timed["passes_timed"])
     head = [float(x) for x in st_timed["pass_ms_head"][:min(8, np_timed)]]
-    pass_ms = st_timed["sum_pass_ms"] / max(1, np_timed)
     first_ms = head[0] if head else None
     second_third = head[1:3]
     n_rest = np_timed - min(np_timed, 4)
     converged_ms = (st_timed["sum_pass_ms"] - sum(head[:4])) / n_rest if n_rest > 0 else None
+    # mean pass over ALL K + 1 passes of the timed region: the first four as timed, the others at the mean of those that carried events
+    n_all = K + 1
+    if np_timed >= n_all or converged_ms is None:
+        pass_ms = st_timed["sum_pass_ms"] / max(1, np_timed)
+    else:
+        pass_ms = (sum(head[:4]) + converged_ms * (n_all - min(4, len(head)))) / n_all
     n_loc = int(eng.local_count())
     passes = dict(first_ms=round(first_ms, 5) if first_ms is not None else None,
                   second_third_ms=[round(x, 5) for x in second_third],
                   converged_ms=round(converged_ms, 5) if converged_ms is not None else None,
-                  timed=np_timed, loop="host" if (args.host_loop or os.environ.get("SYMMICP_HOST_LOOP") == "1" or args.exchange in ("shm", "torch")) else "device")
+                  timed=np_timed, of=K + 1, events="every pass" if (all_events or np_timed >= K + 1) else "every pass of the host loop, every 4th pass of a device-driven run", loop="host" if (args.host_loop or os.environ.get("SYMMICP_HOST_LOOP") == "1" or args.exchange in ("shm", "torch")) else "device")
 
     # ---- kernel table of the instrumented run ---------------------------------------------------------
     names = symmicp.KERNEL_SLOTS

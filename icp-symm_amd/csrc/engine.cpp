@@ -958,7 +958,7 @@ static int run_pass(symmicp_ctx *c, const float Xapply[16], bool from_cur, bool 
     if (c->timing) {
         if (c->ev_used == symmicp_ctx::kEvRing) flush_events(c);
         ev = c->ev + c->ev_used * symmicp_ctx::kEvPer;
-        c->ev_split[c->ev_used] = (c->timing == 1) ? 1 : 0;
+        c->ev_split[c->ev_used] = (c->timing == 1 || c->timing == 3) ? 1 : 0;
     }
     // (in per-kernel mode the split launcher records ev[0] itself)
     if (ev && !(c->timing == 2 && c->cfg.corr == SYMMICP_CORR_TREE)) hipEventRecord(ev[0], c->stream);
@@ -1149,6 +1149,7 @@ static bool batch_eligible(const symmicp_ctx *c)
 // if symmicp_step had been called (c->iters - iters_before) times; diffs_before[k] = the diff the reference prints before
 // iteration iters_before + 1 + k.  *small_step: the increment rule ended the alignment.
 static constexpr int kListBlocks = 8;      // partial columns of the straggler stage
+static constexpr int kEvSampleStride = 4;  // timing mode 3: passes of a device-driven run that carry events
 static int run_batch(symmicp_ctx *c, int want, float *diffs_before, int *n_done, bool *small_step)
 {
     *n_done = 0;
@@ -1202,7 +1203,9 @@ static int run_batch(symmicp_ctx *c, int want, float *diffs_before, int *n_done,
     // The record of the last complete pass is in d_sums: solve from it, then (pass, reduce, [all-reduce,] solve) per iteration.
     // Passes are enqueued in chunks of 4, 8, 16, ... with one look at the loop state between chunks: a loop that stops early
     // (convergence, a pass that has to be redone) leaves at most one chunk of no-op launches behind.
-    if (c->timing == 1 && c->ev_used + want > symmicp_ctx::kEvRing) flush_events(c);
+    const bool timed_run = c->timing == 1 || c->timing == 3;
+    const int ev_stride = c->timing == 3 ? kEvSampleStride : 1;      // mode 3: every 4th pass of the run
+    if (timed_run && c->ev_used + want > symmicp_ctx::kEvRing) flush_events(c);
     int enq = 0, chunk = 4, n_stage = 0;
     bool first_chunk = true;
     while (enq < want) {
@@ -1219,7 +1222,7 @@ static int run_batch(symmicp_ctx *c, int want, float *diffs_before, int *n_done,
         if (first_chunk) launch_reduce_solve(c->partials, blocks, c->d_sums, 2, c->d_loop, lc, c->h_ring_dev, symmicp_ctx::kRing, counters, c->stream);
         for (int p = 0; p < nq; p++) {
             hipEvent_t *ev = nullptr;
-            if (c->timing == 1 && c->ev_used < symmicp_ctx::kEvRing) {
+            if (timed_run && (enq + p) % ev_stride == 0 && c->ev_used < symmicp_ctx::kEvRing) {
                 ev = c->ev + c->ev_used * symmicp_ctx::kEvPer;
                 c->ev_split[c->ev_used] = 1;
                 hipEventRecord(ev[0], c->stream);
@@ -1267,7 +1270,11 @@ static int run_batch(symmicp_ctx *c, int want, float *diffs_before, int *n_done,
         // passes of this chunk that did run (a pass that has to be redone ran too); the events of the no-op launches behind a
         // stop are dropped
         const int ran = (c->h_loop->iters - it_before) + (c->h_loop->reason == LOOP_REDO_PASS ? 1 : 0);
-        if (c->timing == 1 && ran >= 0 && ev_used0 + ran < c->ev_used) c->ev_used = ev_used0 + ran;
+        if (timed_run && ran >= 0) {
+            int sampled_ran = 0;                      // event pairs of the passes that ran
+            for (int p = 0; p < ran && p < nq; p++) sampled_ran += ((enq - nq + p) % ev_stride == 0) ? 1 : 0;
+            if (ev_used0 + sampled_ran < c->ev_used) c->ev_used = ev_used0 + sampled_ran;
+        }
         if (stragglers) n_stage += c->h_loop->iters - it_before;
         if (c->h_loop->stop) break;
         if (tree && !no_stage) {
@@ -1728,7 +1735,7 @@ int symmicp_set_sums(symmicp_ctx *c, const symmicp_sums *total)
 int symmicp_enable_timing(symmicp_ctx *c, int on)
 {
     if (!c) return SYMMICP_ERR_ARG;
-    c->timing = on < 0 ? 0 : (on > 2 ? 2 : on);
+    c->timing = on < 0 ? 0 : (on > 3 ? 3 : on);
     return SYMMICP_OK;
 }
 

@@ -686,7 +686,7 @@ def test_bench_line_keeps_its_contract():
     assert cb["all_cores"]["value"] > 0 and cb["all_cores"]["cores"] == os.cpu_count()
     # what was measured: pass durations by regime, the cold exact-NN rate, each regime against the resource that bounds it
     ps = d["passes"]
-    assert ps["first_ms"] > 0 and len(ps["second_third_ms"]) == 2 and ps["converged_ms"] > 0 and ps["timed"] == 7 and ps["loop"] in ("device", "host")
+    assert ps["first_ms"] > 0 and len(ps["second_third_ms"]) == 2 and ps["converged_ms"] > 0 and 5 <= ps["timed"] <= 7 and ps["of"] == 7 and ps["events"] and ps["loop"] in ("device", "host")
     assert abs(d["mcorr_per_sec_first_pass"] - 20000 / (ps["first_ms"] * 1e-3) / 1e6) < 1e-2 * d["mcorr_per_sec_first_pass"]
     rr = d["roofline_by_regime"]
     assert [e["bound"] for e in rr] == ["valu", "valu", "hbm"] and all(e["kernel"] and e["model"] and e["ms"] > 0 for e in rr)
