@@ -245,7 +245,7 @@ def main():
     passes = dict(first_ms=round(first_ms, 5) if first_ms is not None else None,
                   second_third_ms=[round(x, 5) for x in second_third],
                   converged_ms=round(converged_ms, 5) if converged_ms is not None else None,
-                  timed=np_timed, of=K + 1, events="every pass" if (all_events or np_timed >= K + 1) else "every pass of the host loop, every 4th pass of a device-driven run", loop="host" if (args.host_loop or os.environ.get("SYMMICP_HOST_LOOP") == "1" or args.exchange in ("shm", "torch")) else "device")
+                  timed=np_timed, of=K + 1, events="every pass" if (all_events or no_events) else "every pass of the host loop, every 4th pass of a device-driven run (standing for the three behind it)", loop="host" if (args.host_loop or os.environ.get("SYMMICP_HOST_LOOP") == "1" or args.exchange in ("shm", "torch")) else "device")
 
     # ---- kernel table of the instrumented run ---------------------------------------------------------
     names = symmicp.KERNEL_SLOTS

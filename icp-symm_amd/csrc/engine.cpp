@@ -175,6 +175,7 @@ struct symmicp_ctx {
     static constexpr int kEvRing = 64, kEvPer = 6;
     hipEvent_t ev[kEvRing * kEvPer] = {};
     int ev_split[kEvRing] = {};      // 1 = split TREE pass (5 kernels), 0 = single pass kernel
+    int ev_weight[kEvRing] = {};     // passes this entry stands for (timing mode 3 samples the passes of a device-driven run)
     int ev_used = 0;
     symmicp_stats st{};
     // host-side timing of the pass loop, printed by symmicp_destroy under SYMMICP_DEBUG_HOST
@@ -863,10 +864,11 @@ static void flush_events(symmicp_ctx *c)
             if (hipEventElapsedTime(&ms, e[0], e[4]) == hipSuccess) { c->st.kernel_ms[5] += ms; c->st.kernel_launches[5]++; pass_ms += ms; }
             if (hipEventElapsedTime(&ms, e[4], e[5]) == hipSuccess) { c->st.kernel_ms[4] += ms; c->st.kernel_launches[4]++; }
         }
+        const int w = c->ev_weight[p] > 0 ? c->ev_weight[p] : 1;
         c->st.last_pass_ms = pass_ms;
-        c->st.sum_pass_ms += pass_ms;
+        c->st.sum_pass_ms += pass_ms * w;
         if (c->st.passes_timed < 8) c->st.pass_ms_head[c->st.passes_timed] = pass_ms;
-        c->st.passes_timed++;
+        c->st.passes_timed += w;
     }
     c->ev_used = 0;
 }
@@ -959,6 +961,7 @@ static int run_pass(symmicp_ctx *c, const float Xapply[16], bool from_cur, bool 
         if (c->ev_used == symmicp_ctx::kEvRing) flush_events(c);
         ev = c->ev + c->ev_used * symmicp_ctx::kEvPer;
         c->ev_split[c->ev_used] = (c->timing == 1 || c->timing == 3) ? 1 : 0;
+        c->ev_weight[c->ev_used] = 1;
     }
     // (in per-kernel mode the split launcher records ev[0] itself)
     if (ev && !(c->timing == 2 && c->cfg.corr == SYMMICP_CORR_TREE)) hipEventRecord(ev[0], c->stream);
@@ -1225,6 +1228,7 @@ static int run_batch(symmicp_ctx *c, int want, float *diffs_before, int *n_done,
             if (timed_run && (enq + p) % ev_stride == 0 && c->ev_used < symmicp_ctx::kEvRing) {
                 ev = c->ev + c->ev_used * symmicp_ctx::kEvPer;
                 c->ev_split[c->ev_used] = 1;
+                c->ev_weight[c->ev_used] = 1;
                 hipEventRecord(ev[0], c->stream);
             }
             if (tree) {
@@ -1271,8 +1275,15 @@ static int run_batch(symmicp_ctx *c, int want, float *diffs_before, int *n_done,
         // stop are dropped
         const int ran = (c->h_loop->iters - it_before) + (c->h_loop->reason == LOOP_REDO_PASS ? 1 : 0);
         if (timed_run && ran >= 0) {
-            int sampled_ran = 0;                      // event pairs of the passes that ran
-            for (int p = 0; p < ran && p < nq; p++) sampled_ran += ((enq - nq + p) % ev_stride == 0) ? 1 : 0;
+            int sampled_ran = 0;                      // event pairs of the passes that ran; each stands for the passes up to the next pair
+            for (int p = 0; p < ran && p < nq; p++) {
+                if ((enq - nq + p) % ev_stride != 0) continue;
+                if (ev_used0 + sampled_ran < symmicp_ctx::kEvRing) {
+                    const int left = (ran < nq ? ran : nq) - p;
+                    c->ev_weight[ev_used0 + sampled_ran] = left < ev_stride ? left : ev_stride;
+                }
+                sampled_ran++;
+            }
             if (ev_used0 + sampled_ran < c->ev_used) c->ev_used = ev_used0 + sampled_ran;
         }
         if (stragglers) n_stage += c->h_loop->iters - it_before;

@@ -231,7 +231,7 @@ typedef struct {
 int symmicp_get_stats(symmicp_ctx *ctx, symmicp_stats *out);
 int symmicp_reset_stats(symmicp_ctx *ctx);
 /* HIP events on the ctx stream: 0 off, 1 two events bracketing each pass, 2 events around every kernel of a pass, 3 as 1 but only
- * every 4th pass of a device-driven run of iterations (each record costs ~2.5 us of GPU timeline: two per pass are 13 % of a converged
+ * every 4th pass of a device-driven run of iterations carries events and stands for its neighbours in the sums (each record costs ~2.5 us of GPU timeline: two per pass are 13 % of a converged
  * 1M-point iteration; mode 2 is for profiling, not for throughput runs) */
 int symmicp_enable_timing(symmicp_ctx *ctx, int on);
 
