@@ -867,7 +867,7 @@ static void flush_events(symmicp_ctx *c)
         const int w = c->ev_weight[p] > 0 ? c->ev_weight[p] : 1;
         c->st.last_pass_ms = pass_ms;
         c->st.sum_pass_ms += pass_ms * w;
-        if (c->st.passes_timed < 8) c->st.pass_ms_head[c->st.passes_timed] = pass_ms;
+        for (int k = 0; k < w && c->st.passes_timed + k < 8; k++) c->st.pass_ms_head[c->st.passes_timed + k] = pass_ms;      // (a sampled pass stands for w passes)
         c->st.passes_timed += w;
     }
     c->ev_used = 0;
