@@ -1209,7 +1209,10 @@ static int run_batch(symmicp_ctx *c, int want, float *diffs_before, int *n_done,
     const bool timed_run = c->timing == 1 || c->timing == 3;
     const int ev_stride = c->timing == 3 ? kEvSampleStride : 1;      // mode 3: every 4th pass of the run
     if (timed_run && c->ev_used + want > symmicp_ctx::kEvRing) flush_events(c);
-    int enq = 0, chunk = 4, n_stage = 0;
+    // (a run that only a bail-out can stop -- fixed iteration count, no increment criterion, no work list at entry -- is enqueued in one
+    // piece: every chunk boundary is a host look at the loop state, ~12 us of idle GPU)
+    const bool unstoppable = lc.fixed_iters && !(lc.eps_rotation > 0.f && lc.eps_translation > 0.f) && !stragglers;
+    int enq = 0, chunk = unstoppable ? want : 4, n_stage = 0;
     bool first_chunk = true;
     while (enq < want) {
         const int nq = (want - enq < chunk) ? want - enq : chunk;
