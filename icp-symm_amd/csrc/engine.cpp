@@ -833,7 +833,7 @@ int symmicp_set_source(symmicp_ctx *c, const float *xyz, size_t xr, size_t xc, c
             HIP_TRY(c, hipMemcpyAsync(&npk, cnt.p, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
             HIP_TRY(c, hipStreamSynchronize(c->stream));
             if (npk < nblk || npk > cap) { forget_source(c); return fail(c, SYMMICP_ERR_HIP, "packet table: count out of range"); }
-            radix_sort_pairs(keys.p, vals.p, kt.p, vt.p, npk, key_bits, ws.p, wse, c->stream);
+            radix_sort_pairs(keys.p, vals.p, kt.p, vt.p, npk, key_bits > 0 ? key_bits : 32, ws.p, wse, c->stream);
             c->pkt_tab = reinterpret_cast<uint32_t *>(c->src_all + o_pkt);
             c->pkt_count = npk;
             launch_packet_table(vals.p, runs.p, npk, reinterpret_cast<uint2 *>(c->pkt_tab), c->stream);

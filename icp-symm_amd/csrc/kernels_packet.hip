@@ -572,7 +572,8 @@ __global__ __launch_bounds__(64) void k_packet_runs(CloudSoA src, uint32_t n, fl
     if (active && lane == start) {
         const uint32_t k = atomicAdd(count, 1u);
         runs[k] = make_uint2(i, (uint32_t)(end - start));
-        keys[k] = key_bits >= 32 ? ~__float_as_uint(r2) : ((1u << key_bits) - 1u) - (__float_as_uint(r2) >> (32 - key_bits));
+        // (key_bits <= 0: Morton order, the key is the run's first query)
+        keys[k] = key_bits <= 0 ? i : (key_bits >= 32 ? ~__float_as_uint(r2) : ((1u << key_bits) - 1u) - (__float_as_uint(r2) >> (32 - key_bits)));
         vals[k] = k;
     }
 }
