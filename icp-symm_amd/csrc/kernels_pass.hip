@@ -395,9 +395,10 @@ __device__ __forceinline__ void cells_tile(const PassArgs &a, const TargetIndex 
     __shared__ uint32_t s_second[kPassThreads];        // d2 bits of the second-nearest scanned point
     __shared__ int32_t s_pos[kPassThreads];
     __shared__ uint32_t s_cell0[kPassThreads];
-    __shared__ uint16_t s_items[kPassThreads * 27];
+    __shared__ __align__(8) uint16_t s_items[kPassThreads * 27];       // (the free tail also holds the 8-byte sub-items of crowded cells)
     __shared__ uint32_t s_wsum[kPassThreads / 64 + 1];
     __shared__ uint32_t s_anyw[kPassThreads / 64];     // per-wave flags for block-wide "any" votes
+    __shared__ uint32_t s_nmore;                       // sub-items of crowded cells (phase 2)
     constexpr int kHoodLds = HOOD ? kPassThreads : 1;
     __shared__ float s_reach[kHoodLds];                // T of the query's neighbourhood (0: none wanted)
     __shared__ uint32_t s_hcnt[kHoodLds];              // scanned points closer than T (the first 8 go straight to certk)
@@ -601,33 +602,32 @@ __device__ __forceinline__ void cells_tile(const PassArgs &a, const TargetIndex 
             m &= m - 1;
             s_items[slot++] = (uint16_t)((tid << 5) | bit);
         }
+        if (tid == 0) s_nmore = 0;
     }
     __syncthreads();
     // ---- phase 2 ----
-    for (uint32_t it0 = 0; it0 < total; it0 += kPassThreads) {
-        const uint32_t it = it0 + tid;
+    // One thread scans one (query, cell) item -- at most kItemMax points of it: the rest of a crowded cell (the inner rings of a scan hold
+    // ~100 points per finest cell) is handed over in chunks of kItemMax points, as sub-items in the free tail of the item array that the
+    // whole block scans afterwards.  A wave's cost is then bounded by kItemMax points per lane, not by the most crowded cell among its 64 items.
+    constexpr uint32_t kItemMax = 16;          // (8 / 32: the same within noise on the 2M scan pair)
+    uint2 *s_more = reinterpret_cast<uint2 *>(s_items + ((total + 3u) & ~3u));          // (8-byte aligned: 4 uint16)
+    const uint32_t more_cap = (uint32_t)(kPassThreads * 27 - ((total + 3u) & ~3u)) / 4u;
+    // scan target points [j0, j1) for query q and merge the result into the query's (nearest, second nearest, position); every thread
+    // of the block calls it (have = false: nothing to scan) -- it contains a barrier
+    auto scan_merge = [&](bool have, int q, uint32_t j0, uint32_t j1) {
         unsigned long long mykey = ~0ull;
-        uint32_t my2nd = 0x7f800000u;          // d2 bits of this item's second-nearest point
+        uint32_t my2nd = 0x7f800000u;          // d2 bits of this range's second-nearest point
         int32_t mypos = -1;
-        int q = 0;
-        if (it < total) {
-            const uint32_t item = s_items[it];
-            q = (int)(item >> 5);
-            const int bit = (int)(item & 31u);
-            const int kz = bit / 9, ky = (bit - 9 * kz) / 3, kx = bit - 9 * kz - 3 * ky;
-            const uint32_t c0 = s_cell0[q];
-            const uint32_t cx = (c0 & 1023u) + (uint32_t)kx, cy = ((c0 >> 10) & 1023u) + (uint32_t)ky, cz = (c0 >> 20) + (uint32_t)kz;
-            const uint2 rng = cell_range(ix, (spread3(cz) << 2) | (spread3(cy) << 1) | spread3(cx));
+        if (have) {
             const float qx = s_px[q], qy = s_py[q], qz = s_pz[q];
             const float t2 = HOOD ? s_reach[q] * s_reach[q] : 0.0f;
-            if (ix.dbg) atomicAdd(ix.dbg + 3, (unsigned long long)(rng.y - rng.x));
-            for (uint32_t j = rng.x; j < rng.y; j += 4) {
+            for (uint32_t j = j0; j < j1; j += 4) {
                 float4 t4[4];
 #pragma unroll
-                for (int k = 0; k < 4; k++) t4[k] = ix.tq[min(j + (uint32_t)k, rng.y - 1)];
+                for (int k = 0; k < 4; k++) t4[k] = ix.tq[min(j + (uint32_t)k, j1 - 1)];
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
-                    if (j + (uint32_t)k < rng.y) {
+                    if (j + (uint32_t)k < j1) {
                         const float d2 = dist2(qx, qy, qz, t4[k].x, t4[k].y, t4[k].z);
                         if (HOOD && d2 < t2) {                         // a member of the query's neighbourhood
                             const uint32_t hs = atomicAdd(&s_hcnt[q], 1u);
@@ -656,6 +656,43 @@ __device__ __forceinline__ void cells_tile(const PassArgs &a, const TargetIndex 
         }
         __syncthreads();
         if (mypos >= 0 && s_key[q] == mykey) s_pos[q] = mypos;
+    };
+    for (uint32_t it0 = 0; it0 < total; it0 += kPassThreads) {
+        const uint32_t it = it0 + tid;
+        int q = 0;
+        uint32_t j0 = 0, j1 = 0;
+        if (it < total) {
+            const uint32_t item = s_items[it];
+            q = (int)(item >> 5);
+            const int bit = (int)(item & 31u);
+            const int kz = bit / 9, ky = (bit - 9 * kz) / 3, kx = bit - 9 * kz - 3 * ky;
+            const uint32_t c0 = s_cell0[q];
+            const uint32_t cx = (c0 & 1023u) + (uint32_t)kx, cy = ((c0 >> 10) & 1023u) + (uint32_t)ky, cz = (c0 >> 20) + (uint32_t)kz;
+            const uint2 rng = cell_range(ix, (spread3(cz) << 2) | (spread3(cy) << 1) | spread3(cx));
+            if (ix.dbg) atomicAdd(ix.dbg + 3, (unsigned long long)(rng.y - rng.x));
+            j0 = rng.x; j1 = rng.y;
+            // a crowded cell: chunks are handed over from the end while the tail has room; what is left stays with this thread
+            while (j1 > j0 && j1 - j0 > kItemMax) {
+                const uint32_t js = j0 + ((j1 - j0 - 1u) / kItemMax) * kItemMax;      // start of the last chunk
+                const uint32_t e = atomicAdd(&s_nmore, 1u);
+                if (e >= more_cap) break;
+                s_more[e] = make_uint2((uint32_t)q | ((j1 - js) << 8), js);
+                j1 = js;
+            }
+        }
+        scan_merge(it < total && j1 > j0, q, j0, j1);
+    }
+    __syncthreads();
+    // sub-items of crowded cells
+    {
+        const uint32_t nmore = min(s_nmore, more_cap);
+        for (uint32_t e0 = 0; e0 < nmore; e0 += kPassThreads) {
+            const uint32_t e = e0 + tid;
+            int q = 0;
+            uint32_t j0 = 0, j1 = 0;
+            if (e < nmore) { const uint2 m = s_more[e]; q = (int)(m.x & 255u); j0 = m.y; j1 = m.y + (m.x >> 8); }
+            scan_merge(e < nmore && j1 > j0, q, j0, j1);
+        }
     }
     __syncthreads();
 
