@@ -221,7 +221,8 @@ typedef struct {
     double kernel_ms[8];
     int64_t kernel_launches[8];
     /* timing on: duration of each of the first 8 passes since symmicp_reset_stats (pass 0 = the correspondence pass of
-     * symmicp_begin, myicp.cpp:122), and how many passes were timed in all */
+     * symmicp_begin, myicp.cpp:122), and how many passes were timed in all (timing mode 3: a pass that carried events counts, in
+     * sum_pass_ms / passes_timed / pass_ms_head, for itself and the up to three passes behind it that carried none) */
     double pass_ms_head[8];
     int64_t passes_timed;
     /* passes that ran inside device-driven runs of iterations (symmicp_align), and those of them that carried the straggler stage
