@@ -77,6 +77,65 @@ double now_s()
 }
 }  // namespace
 
+// Every SYMMICP_* environment switch, read ONCE in symmicp_create (A/B runs and tests; none is needed in production -- DESIGN.md 6 lists
+// them).  Nothing on the pass loop calls getenv.
+struct Switches {
+    bool allow_any_arch = false, debug_host = false, debug_counters = false;
+    std::string debug_trace;               // per-packet trace file of the first pass ("" = off)
+    double grid_ppc = 2.0;                 // points per occupied cell the grid level is chosen for
+    int grid_maxlevel = kMortonBits, grid_level = -1;      // -1: chosen from the cloud; 0 disables the grid phase
+    int first_pass = -1;                   // -1: decided per target (build_index); 0: per-thread walk; 1: packets
+    int oct_leaf = 0;                      // octree leaf size (0: 16 on surface-like targets, 8 otherwise)
+    bool packet_order = true;              // packets started longest-first
+    float packet_jump = -1.0f;             // cut factor of k_packet_runs (< 0: the default, 0: never cut)
+    int packet_key_bits = 16;
+    uint32_t packet_chunk = 0, packet_lds_pad = 0, packet_waves = 0, packet_front_cap = 0;
+    bool no_hood = false, no_cert = false, walk_full_grid = false, host_loop = false, no_loop_stragglers = false, force_comm = false;
+    int budget_walk = -1, optimistic = -1, compact = -1;      // -1 auto, 0 never, 1 always
+    int pass_blocks = 2048, id_blocks = 2048, acc_blocks = 512, fused_blocks = 512, compact_blocks = 1280;
+    PassTuning tune;                       // wave_mode_max, cells_chunk, walk_budget
+};
+
+static void read_switches(Switches &w)
+{
+    auto flag = [](const char *n) { return std::getenv(n) != nullptr; };
+    auto num = [](const char *n, long def) { const char *e = std::getenv(n); return e ? std::atol(e) : def; };
+    auto tri = [](const char *n) { const char *e = std::getenv(n); return e ? (e[0] == '1' ? 1 : 0) : -1; };
+    w.allow_any_arch = flag("SYMMICP_ALLOW_ANY_ARCH");
+    w.debug_host = flag("SYMMICP_DEBUG_HOST");
+    w.debug_counters = flag("SYMMICP_DEBUG_COUNTERS");
+    if (const char *e = std::getenv("SYMMICP_DEBUG_TRACE")) w.debug_trace = e;
+    if (const char *e = std::getenv("SYMMICP_GRID_PPC")) w.grid_ppc = std::atof(e);
+    w.grid_maxlevel = (int)num("SYMMICP_GRID_MAXLEVEL", kMortonBits);
+    w.grid_level = (int)num("SYMMICP_GRID_LEVEL", -1);
+    if (const char *e = std::getenv("SYMMICP_FIRST_PASS")) w.first_pass = (e[0] == 'p') ? 1 : 0;      // "packet" / "walk"
+    w.oct_leaf = (int)num("SYMMICP_OCT_LEAF", 0);
+    if (const char *e = std::getenv("SYMMICP_PACKET_ORDER")) w.packet_order = e[0] != '0';
+    if (const char *e = std::getenv("SYMMICP_PACKET_JUMP")) w.packet_jump = (float)std::atof(e);
+    w.packet_key_bits = (int)num("SYMMICP_PACKET_KEY_BITS", 16);
+    w.packet_chunk = (uint32_t)num("SYMMICP_PACKET_CHUNK", 0);
+    w.packet_lds_pad = (uint32_t)num("SYMMICP_PACKET_LDS_PAD", 0);
+    w.packet_waves = (uint32_t)num("SYMMICP_PACKET_WAVES", 0);
+    w.packet_front_cap = (uint32_t)num("SYMMICP_PACKET_FRONT_CAP", 0);
+    w.no_hood = flag("SYMMICP_NO_NEIGHBOURHOOD");
+    w.no_cert = flag("SYMMICP_NO_CERT");
+    w.walk_full_grid = flag("SYMMICP_WALK_FULL_GRID");
+    { const char *e = std::getenv("SYMMICP_HOST_LOOP"); w.host_loop = e && e[0] == '1'; }
+    w.no_loop_stragglers = flag("SYMMICP_NO_LOOP_STRAGGLERS");
+    w.force_comm = flag("SYMMICP_FORCE_COMM");
+    w.budget_walk = tri("SYMMICP_BUDGET_WALK");
+    w.optimistic = tri("SYMMICP_OPTIMISTIC");
+    w.compact = tri("SYMMICP_COMPACT");
+    w.pass_blocks = (int)num("SYMMICP_PASS_BLOCKS", 2048);
+    w.id_blocks = (int)num("SYMMICP_ID_BLOCKS", 2048);
+    w.acc_blocks = (int)num("SYMMICP_ACC_BLOCKS", 512);
+    w.fused_blocks = (int)num("SYMMICP_FUSED_BLOCKS", 512);
+    w.compact_blocks = (int)num("SYMMICP_COMPACT_BLOCKS", 1280);
+    w.tune.wave_mode_max = (uint32_t)num("SYMMICP_WAVE_MODE_MAX", 20000);
+    w.tune.cells_chunk = (uint32_t)num("SYMMICP_CELLS_CHUNK", 16);
+    w.tune.walk_budget = (uint32_t)num("SYMMICP_WALK_BUDGET", 160);
+}
+
 // Scratch arena of a context: the builds need dozens of temporaries, and every hipFree costs ~100 us (it synchronises the
 // device) -- half of a set_target + set_source at 1M points.  Temporaries are bump-allocated from one block that is
 // rewound at the start of each public call and only ever grows; persistent results are hipMalloc'ed as before.
@@ -104,6 +163,7 @@ struct ShmExchange {
 };
 
 struct symmicp_ctx {
+    Switches sw;                     // environment switches as they stood at symmicp_create
     Arena arena;                     // temporaries of one public call
     Arena keep;                      // the target's persistent arrays (reused by the next set_target)
     std::vector<void *> keep_extra;  // ... and those that did not fit
@@ -147,6 +207,7 @@ struct symmicp_ctx {
     float *hoodr = nullptr;          // ... (T, radius hint) per source point
     uint32_t *pkt_tab = nullptr;     // TREE: the first pass's packets, (first query, count) in start order (widest first)
     uint32_t pkt_count = 0;
+    uint32_t *pkt_fallbacks = nullptr;  // device counter: packets of first passes that finished depth-first (k_search_packet)
     unsigned long long *best64 = nullptr;
     uint32_t *worklist = nullptr, *wl_count = nullptr;   // the sharded work list + its counters
     WorkLists wl{};
@@ -294,6 +355,7 @@ int symmicp_create(const symmicp_config *cfg, symmicp_ctx **out)
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return SYMMICP_ERR_HIP;   // no CPU fallback
     symmicp_ctx *c = new symmicp_ctx();
+    read_switches(c->sw);
     c->cfg = *cfg;
     if (cfg->device >= 0) {
         if (cfg->device >= ndev || hipSetDevice(cfg->device) != hipSuccess) { delete c; return SYMMICP_ERR_HIP; }
@@ -301,7 +363,7 @@ int symmicp_create(const symmicp_config *cfg, symmicp_ctx **out)
     } else if (hipGetDevice(&c->device) != hipSuccess) { delete c; return SYMMICP_ERR_HIP; }
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, c->device) != hipSuccess) { delete c; return SYMMICP_ERR_HIP; }
-    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0 && !std::getenv("SYMMICP_ALLOW_ANY_ARCH")) {
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0 && !c->sw.allow_any_arch) {
         // the code object only carries gfx950 ISA
         delete c;
         return SYMMICP_ERR_HIP;
@@ -310,7 +372,7 @@ int symmicp_create(const symmicp_config *cfg, symmicp_ctx **out)
     bool ok = hipMalloc((void **)&c->partials, sizeof(double) * kNSum * 8192) == hipSuccess &&
               hipMalloc((void **)&c->d_sums, sizeof(double) * kNSum) == hipSuccess &&
               hipHostMalloc((void **)&c->h_sums, sizeof(double) * (kNSum + 8), hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess &&
-              hipMalloc((void **)&c->ticket, sizeof(uint32_t)) == hipSuccess && hipMemset(c->ticket, 0, sizeof(uint32_t)) == hipSuccess &&
+              hipMalloc((void **)&c->ticket, 2 * sizeof(uint32_t)) == hipSuccess && hipMemset(c->ticket, 0, 2 * sizeof(uint32_t)) == hipSuccess &&
               hipHostGetDevicePointer((void **)&c->h_sums_dev, c->h_sums, 0) == hipSuccess &&
               std::memset(c->h_sums, 0, sizeof(double) * (kNSum + 8)) != nullptr &&
               hipMalloc((void **)&c->d_loop, sizeof(LoopState)) == hipSuccess &&
@@ -324,6 +386,7 @@ int symmicp_create(const symmicp_config *cfg, symmicp_ctx **out)
               true;
     for (int k = 0; ok && k < symmicp_ctx::kEvRing * symmicp_ctx::kEvPer; k++) ok = hipEventCreateWithFlags(&c->ev[k], hipEventDisableSystemFence) == hipSuccess;      // timing only: no system-scope cache flush per record
     if (!ok) { symmicp_destroy(c); return SYMMICP_ERR_HIP; }
+    c->pkt_fallbacks = c->ticket + 1;
     identity16(c->X);
     *out = c;
     return SYMMICP_OK;
@@ -369,7 +432,7 @@ static void free_source(symmicp_ctx *c)
 void symmicp_destroy(symmicp_ctx *c)
 {
     if (!c) return;
-    if (std::getenv("SYMMICP_DEBUG_HOST") && c->n_pass_timed)
+    if (c->sw.debug_host && c->n_pass_timed)
         std::fprintf(stderr, "[symmicp host] passes %ld: launch %.1f us, spin %.1f us, between passes %.1f us (per pass)\n", c->n_pass_timed, 1e6 * c->t_launch / c->n_pass_timed, 1e6 * c->t_spin / c->n_pass_timed, 1e6 * c->t_between / c->n_pass_timed);
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
@@ -562,10 +625,8 @@ static int build_index(symmicp_ctx *c, const CloudSoA &cl, uint32_t n, bool want
         HIP_TRY(c, hipMemcpyAsync(hh, hist.p, sizeof(hh), hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         // finest level whose occupied cells still hold >= ppc points on average
-        double ppc = 2.0;
-        if (const char *e = std::getenv("SYMMICP_GRID_PPC")) ppc = std::atof(e);
-        int lcap = kMortonBits;                          // the table is two-level: memory follows the occupied super-cells
-        if (const char *e = std::getenv("SYMMICP_GRID_MAXLEVEL")) lcap = std::atoi(e);
+        const double ppc = c->sw.grid_ppc;
+        int lcap = c->sw.grid_maxlevel;                  // the table is two-level: memory follows the occupied super-cells
         if (lcap > kMortonBits) lcap = kMortonBits;
         glevel = 1;
         double occ = 1.0;
@@ -573,7 +634,7 @@ static int build_index(symmicp_ctx *c, const CloudSoA &cl, uint32_t n, bool want
             occ += (double)hh[l];
             if ((double)n / occ >= ppc) glevel = l;
         }
-        if (const char *e = std::getenv("SYMMICP_GRID_LEVEL")) glevel = std::atoi(e);   // 0 disables the grid phase
+        if (c->sw.grid_level >= 0) glevel = c->sw.grid_level;   // 0 disables the grid phase
         if (glevel > lcap) glevel = lcap;
         if (glevel < 0) glevel = 0;
         // Is the target a surface or a volume?  Occupied cells grow ~4x per octree level on a surface and ~8x in a volume
@@ -590,7 +651,7 @@ static int build_index(symmicp_ctx *c, const CloudSoA &cl, uint32_t n, bool want
             const int lg = glevel >= 2 ? glevel - 1 : 1;
             const double growth = occ_l[lg] / occ_l[lg - 1];
             c->target_surface_like = growth < 5.5;
-            if (const char *e = std::getenv("SYMMICP_FIRST_PASS")) c->target_surface_like = (e[0] == 'p');      // "packet" / "walk": A/B runs
+            if (c->sw.first_pass >= 0) c->target_surface_like = c->sw.first_pass == 1;      // SYMMICP_FIRST_PASS=packet|walk: A/B runs
         }
     }
     ix.glevel = glevel;
@@ -650,7 +711,7 @@ static int build_index(symmicp_ctx *c, const CloudSoA &cl, uint32_t n, bool want
     HIP_TRY(c, hipGetLastError());
     if (onodes_out) {
         uint32_t leaf_max = c->target_surface_like ? 16u : 8u;
-        if (const char *e = std::getenv("SYMMICP_OCT_LEAF")) leaf_max = (uint32_t)std::atoi(e);
+        if (c->sw.oct_leaf > 0) leaf_max = (uint32_t)c->sw.oct_leaf;
         st = build_octree(c, keys.p, tq, n, leaf_max, onodes_out, &ix);
         if (st != SYMMICP_OK) return st;
     }
@@ -705,14 +766,14 @@ int symmicp_set_target(symmicp_ctx *c, const float *xyz, size_t xr, size_t xc, c
     st = build_index(c, c->tgt, c->n_t, /*want_grid=*/true, c->tq, c->tn, &c->boxes, &c->cells, &c->ix, &c->st.grid_level, &c->st.tree_levels,
                      &c->onodes, &c->ctop);
     if (st != SYMMICP_OK) { free_target(c); return st; }
-    if (std::getenv("SYMMICP_DEBUG_COUNTERS")) {
+    if (c->sw.debug_counters) {
         HIP_TRY(c, hipMalloc((void **)&c->dbg, 12 * sizeof(unsigned long long)));
         HIP_TRY(c, hipMemset(c->dbg, 0, 12 * sizeof(unsigned long long)));
         c->ix.dbg = c->dbg;
     }
-    if (std::getenv("SYMMICP_DEBUG_TRACE")) {          // (alone: the production kernel with a timing-only trace)
-        HIP_TRY(c, hipMalloc((void **)&c->dbg_trace, ((size_t)1 << 21) * 16));
-        HIP_TRY(c, hipMemset(c->dbg_trace, 0, ((size_t)1 << 21) * 16));
+    if (!c->sw.debug_trace.empty()) {          // (alone: the production kernel with a timing-only trace)
+        HIP_TRY(c, hipMalloc((void **)&c->dbg_trace, ((size_t)1 << 22) * 8));      // (kTraceWords)
+        HIP_TRY(c, hipMemset(c->dbg_trace, 0, ((size_t)1 << 22) * 8));
         c->ix.dbg_trace = c->dbg_trace;
     }
     c->have_index = true;
@@ -737,7 +798,7 @@ int symmicp_set_source(symmicp_ctx *c, const float *xyz, size_t xr, size_t xc, c
     symmicp_shard_range(n, c->nranks, c->rank, &b0, &bc);
     const size_t nu = bc > 0 ? bc : 1;                       // rows uploaded (an empty share still stages one row)
     const size_t r0 = bc > 0 ? b0 : 0;
-    arena_begin(c->arena, nu * (52 + 4 * (xr + nr)) + ((size_t)1 << 20));      // (+4 B per point: the packet table's temporaries)
+    arena_begin(c->arena, nu * (56 + 4 * (xr + nr)) + ((size_t)1 << 20));      // (+8 B per point: the packet table's temporaries)
     DevBuf<float> full;
     int st = upload_planar(c, xyz + r0 * xr, xr, xc, nrm + r0 * nr, nr, nc, nu, full, /*temp=*/true, nullptr);
     if (st != SYMMICP_OK) return st;
@@ -757,7 +818,7 @@ int symmicp_set_source(symmicp_ctx *c, const float *xyz, size_t xr, size_t xc, c
     const size_t o_best = brute ? take(sizeof(unsigned long long) * nl) : 0;
     const size_t o_cert = tree ? take(sizeof(float) * 4 * nl) : 0;
     const size_t o_certk = tree ? take(sizeof(uint32_t) * 8 * nl) : 0, o_hoodr = tree ? take(sizeof(float) * 2 * nl) : 0;
-    const size_t o_pkt = tree ? take(sizeof(uint32_t) * 2 * 4 * ((nl + 63) / 64)) : 0;        // (a block of 64 queries may be cut into 4 packets)
+    const size_t o_pkt = tree ? take(sizeof(uint32_t) * 2 * 8 * ((nl + 63) / 64)) : 0;        // (a block of 64 queries may be cut into 8 packets: kMaxRunsPerBlock)
     const size_t o_prec = tree ? take(sizeof(float4) * 2 * nl) : 0;
     const size_t o_wl = tree ? take(sizeof(uint32_t) * 2 * per_list) : 0, o_cnt = tree ? take(sizeof(uint32_t) * 2 * ncount) : 0;      // work + retry lists
     if (off > c->src_all_cap) {
@@ -810,13 +871,13 @@ int symmicp_set_source(symmicp_ctx *c, const float *xyz, size_t xr, size_t xc, c
         // Measured on the 1M surface pair: 0.81 -> 0.67 ms (only the widest third first: 0.70 -- the Morton order of the rest, i.e. XCD
         // locality, is worth less than the balance; splitting the widest packets into halves / quarters on top: no gain).
         const uint32_t nblk = (c->n_loc + 63u) / 64u;
-        static const bool ordered = !(std::getenv("SYMMICP_PACKET_ORDER") && std::getenv("SYMMICP_PACKET_ORDER")[0] == '0');      // A/B runs
+        const bool ordered = c->sw.packet_order;      // (SYMMICP_PACKET_ORDER=0: packets as they lie)
         c->pkt_tab = nullptr; c->pkt_count = 0;
         if (ordered) {
             // (a block of 64 queries is cut into runs at its jumps of the Morton curve: k_packet_runs)
-            static const float jump = std::getenv("SYMMICP_PACKET_JUMP") ? (float)std::atof(std::getenv("SYMMICP_PACKET_JUMP")) : -1.0f;      // x the block's scale; 0: never cut
-            static const int key_bits = std::getenv("SYMMICP_PACKET_KEY_BITS") ? std::atoi(std::getenv("SYMMICP_PACKET_KEY_BITS")) : 16;      // (with the blocks cut at their jumps the order needs no more: 10 / 12 / 16 / 32 bits all 0.56-0.58 ms; two radix passes instead of four)
-            const uint32_t cap = 4u * nblk;
+            const float jump = c->sw.packet_jump;      // x the block's scale; 0: never cut
+            const int key_bits = c->sw.packet_key_bits;      // (with the blocks cut at their jumps the order needs no more: 10 / 12 / 16 / 32 bits all 0.56-0.58 ms; two radix passes instead of four)
+            const uint32_t cap = 8u * nblk;            // (kMaxRunsPerBlock)
             DevBuf<uint32_t> keys, vals, kt, vt, ws, cnt;
             DevBuf<uint2> runs;
             const size_t wse = radix_sort_ws_elems(cap);
@@ -904,6 +965,19 @@ static int shm_exchange(symmicp_ctx *c, double *rec)
     return SYMMICP_OK;
 }
 
+// SYMMICP_DEBUG_TRACE=file: the per-packet trace of the first pass that has just run (k_search_packet), then cleared for the next one
+static constexpr size_t kTraceWords = (size_t)1 << 22;
+static void dump_packet_trace(symmicp_ctx *c)
+{
+    if (FILE *f = std::fopen(c->sw.debug_trace.c_str(), "wb")) {
+        std::vector<unsigned long long> t(kTraceWords);
+        hipMemcpy(t.data(), c->dbg_trace, t.size() * 8, hipMemcpyDeviceToHost);
+        std::fwrite(t.data(), 8, t.size(), f);
+        std::fclose(f);
+    }
+    hipMemset(c->dbg_trace, 0, kTraceWords * 8);
+}
+
 // ---- one pass over the source share ------------------------------------------------------------
 static void fill_pass_args(symmicp_ctx *c, PassArgs &a, const float Xapply[16], bool from_cur, bool writeback, bool first)
 {
@@ -926,19 +1000,22 @@ static void fill_pass_args(symmicp_ctx *c, PassArgs &a, const float Xapply[16], 
     a.d2_out = (c->cfg.corr == SYMMICP_CORR_IDENTITY) ? nullptr : c->d2;
     a.partials = c->partials;
     a.cert = reinterpret_cast<float4 *>(c->cert);
-    static const bool no_hood = std::getenv("SYMMICP_NO_NEIGHBOURHOOD") != nullptr;      // A/B runs
-    a.certk = no_hood ? nullptr : reinterpret_cast<uint4 *>(c->certk);
+    a.certk = c->sw.no_hood ? nullptr : reinterpret_cast<uint4 *>(c->certk);
     a.hoodr = reinterpret_cast<float2 *>(c->hoodr);
     // neighbourhoods are worth their stores once the alignment is settling (the previous pass searched under half of the pairs)
     a.make_hood = (a.certk && !first && c->last_uncertified >= 0 && c->last_uncertified < (long long)(c->n_s_total / 2)) ? 1 : 0;
     a.pairrec = c->pairrec;
     // sharded runs: the first pass over a small share is bound by its slowest walks, not by throughput
-    static const char *bw_env = std::getenv("SYMMICP_BUDGET_WALK");        // "0" never, "1" always (tests), unset: auto
-    a.budget_walk = bw_env ? (bw_env[0] == '1') : (first && c->nranks > 1 && c->n_loc < 400000u);
-    a.use_slack = (!first && c->cert && !std::getenv("SYMMICP_NO_CERT")) ? 1 : 0;
+    a.budget_walk = c->sw.budget_walk >= 0 ? c->sw.budget_walk : (first && c->nranks > 1 && c->n_loc < 400000u);      // (SYMMICP_BUDGET_WALK: "0" never, "1" always)
+    a.use_slack = (!first && c->cert && !c->sw.no_cert) ? 1 : 0;
     a.loop = nullptr;
     a.pkt_tab = reinterpret_cast<const uint2 *>(c->pkt_tab);
     a.pkt_count = c->pkt_count;
+    a.pkt_waves = c->sw.packet_waves;
+    a.pkt_front_cap = c->sw.packet_front_cap;
+    a.pkt_fallbacks = c->pkt_fallbacks;
+    a.pkt_chunk = c->sw.packet_chunk;
+    a.pkt_lds_pad = c->sw.packet_lds_pad;
 }
 
 static int run_pass(symmicp_ctx *c, const float Xapply[16], bool from_cur, bool writeback, bool first)
@@ -946,8 +1023,7 @@ static int run_pass(symmicp_ctx *c, const float Xapply[16], bool from_cur, bool 
     PassArgs a{};
     fill_pass_args(c, a, Xapply, from_cur, writeback, first);
     int blocks = (int)((c->n_loc + kPassThreads - 1) / kPassThreads);
-    int cap = 2048;
-    if (const char *e = std::getenv("SYMMICP_PASS_BLOCKS")) cap = std::atoi(e);
+    int cap = c->sw.pass_blocks;
     if (cap > 8192) cap = 8192;
     if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
@@ -970,7 +1046,7 @@ static int run_pass(symmicp_ctx *c, const float Xapply[16], bool from_cur, bool 
         // 16-byte column loads need every planar column (length n_loc / n_t) and the shard offset to keep 16-B alignment
         const bool vec4 = (c->n_loc % 4 == 0) && (c->n_t % 4 == 0) && (c->src_off % 4 == 0);
         if (vec4) {
-            static const int id_cap = std::getenv("SYMMICP_ID_BLOCKS") ? std::atoi(std::getenv("SYMMICP_ID_BLOCKS")) : 2048;
+            const int id_cap = c->sw.id_blocks;
             const int nb4 = (int)((c->n_loc / 4 + kPassThreads - 1) / kPassThreads);
             blocks = nb4 < id_cap ? (nb4 > 0 ? nb4 : 1) : id_cap;
             c->pass_blocks = blocks;
@@ -986,7 +1062,7 @@ static int run_pass(symmicp_ctx *c, const float Xapply[16], bool from_cur, bool 
         {
             // the accumulate kernel is streaming with a 40-value block reduction at the end of every block: 2 blocks per
             // CU measured best (18 us at 512 blocks, 23 us at 2048, 1M points); a multiple of 8 for the XCD remap
-            static const int acc_cap = std::getenv("SYMMICP_ACC_BLOCKS") ? std::atoi(std::getenv("SYMMICP_ACC_BLOCKS")) : 512;
+            const int acc_cap = c->sw.acc_blocks;
             const int nb_all = (int)((c->n_loc + kPassThreads - 1) / kPassThreads);
             int ab = nb_all < acc_cap ? ((nb_all + 7) / 8) * 8 : acc_cap;
             if (ab < 8) ab = 8;                     // (a rank whose share is empty still writes its zero record)
@@ -999,13 +1075,12 @@ static int run_pass(symmicp_ctx *c, const float Xapply[16], bool from_cur, bool 
                 if (walk_blocks > 8192u) walk_blocks = 8192u;
             }
             if (!first && c->last_list_len == -2) walk_blocks = 16384u;
-            if (std::getenv("SYMMICP_WALK_FULL_GRID")) walk_blocks = 0;
+            if (c->sw.walk_full_grid) walk_blocks = 0;
             // Once an alignment has converged the work list stays empty (every pair is certified or settled by the cell
             // scan), and an empty walk launch still costs ~6 us of a ~50 us pass.  So after a pass with an empty list the
             // walk is skipped; the final reduce reports the list's length, and in the rare case that it is not empty
             // after all the pass is repaired below (walk, accumulate and reduce again).
-            static const char *opt_env = std::getenv("SYMMICP_OPTIMISTIC");      // "0" never, "1" always (tests), unset: auto
-            optimistic = opt_env ? (opt_env[0] == '1') : (!first && c->last_list_len == 0);
+            optimistic = c->sw.optimistic >= 0 ? c->sw.optimistic == 1 : (!first && c->last_list_len == 0);      // (SYMMICP_OPTIMISTIC: "0" never, "1" always)
             if (writeback) optimistic = false;      // in-place write-back: a repair would transform the cloud twice
             // per-kernel events only in timing mode 2; mode 1 brackets the pass (events 0 and 4)
             if (first && c->target_surface_like) launch_pass_tree_first(a, c->ix, c->wl, ab, c->stream, c->timing == 2 ? ev : nullptr);
@@ -1013,10 +1088,9 @@ static int run_pass(symmicp_ctx *c, const float Xapply[16], bool from_cur, bool 
             {
                 // Sparse scans (the previous pass searched under a tenth of the pairs): the streaming kernel compacts the
                 // failures of several tiles into full scan rounds; blocks enough to fill the chip at 5 waves per SIMD
-                static const char *cp_env = std::getenv("SYMMICP_COMPACT");        // "0" never, "1" always (tests), unset: auto
-                static const int cp_blocks = std::getenv("SYMMICP_COMPACT_BLOCKS") ? std::atoi(std::getenv("SYMMICP_COMPACT_BLOCKS")) : 1280;
-                const bool compact = a.use_slack && (cp_env ? (cp_env[0] == '1') : (c->last_uncertified >= 0 && c->last_uncertified < (long long)(c->n_s_total / 10)));
-                launch_pass_tree_split(a, c->ix, c->wl, ab, walk_blocks, optimistic ? 1 : 0, compact ? cp_blocks : 0, c->stream, c->timing == 2 ? ev : nullptr);
+                const int cp_blocks = c->sw.compact_blocks;
+                const bool compact = a.use_slack && (c->sw.compact >= 0 ? c->sw.compact == 1 : (c->last_uncertified >= 0 && c->last_uncertified < (long long)(c->n_s_total / 10)));
+                launch_pass_tree_split(a, c->ix, c->wl, ab, walk_blocks, optimistic ? 1 : 0, compact ? cp_blocks : 0, c->sw.tune, c->stream, c->timing == 2 ? ev : nullptr);
             }
             if (ev && c->timing == 2) c->ev_split[c->ev_used] = 2;
         }
@@ -1068,35 +1142,18 @@ static int run_pass(symmicp_ctx *c, const float Xapply[16], bool from_cur, bool 
     if (optimistic && list_len > 0) {
         // the walk was skipped but some queries needed it: their pairs are provisional, so are the sums
         c->st.kernel_launches[7]++;
-        launch_pass_tree_split(a, c->ix, c->wl, blocks, list_len <= 50000 ? 8192u : 0u, 2, 0, c->stream, nullptr);
+        launch_pass_tree_split(a, c->ix, c->wl, blocks, list_len <= 50000 ? 8192u : 0u, 2, 0, c->sw.tune, c->stream, nullptr);
         if (ev && c->ev_split[c->ev_used] != 2) hipEventRecord(ev[4], c->stream);
         if (int st = reduce_and_wait(0)) return st;
         if (c->shm.slots) { if (int st = shm_exchange(c, c->h_sums)) return st; }
     }
     if (ev) c->ev_used++;
     c->t_last_done = now_s(); c->n_pass_timed++;
-    if (!c->ix.dbg && c->dbg_trace && first) {
-        if (FILE *f = std::fopen(std::getenv("SYMMICP_DEBUG_TRACE"), "wb")) {
-            std::vector<unsigned long long> t(((size_t)1 << 21) * 2);
-            hipMemcpy(t.data(), c->dbg_trace, t.size() * 8, hipMemcpyDeviceToHost);
-            std::fwrite(t.data(), 8, t.size(), f);
-            std::fclose(f);
-        }
-        hipMemset(c->dbg_trace, 0, ((size_t)1 << 21) * 16);
-    }
+    if (c->dbg_trace && first) dump_packet_trace(c);
     if (c->ix.dbg) {
         unsigned long long h[12];
         hipMemcpy(h, c->ix.dbg, sizeof(h), hipMemcpyDeviceToHost);
         hipMemset(c->ix.dbg, 0, sizeof(h));
-        if (c->dbg_trace && first) {
-            if (FILE *f = std::fopen(std::getenv("SYMMICP_DEBUG_TRACE"), "wb")) {
-                std::vector<unsigned long long> t(((size_t)1 << 21) * 2);
-                hipMemcpy(t.data(), c->dbg_trace, t.size() * 8, hipMemcpyDeviceToHost);
-                std::fwrite(t.data(), 8, t.size(), f);
-                std::fclose(f);
-            }
-            hipMemset(c->dbg_trace, 0, ((size_t)1 << 21) * 16);
-        }
         if (first && c->cfg.corr == SYMMICP_CORR_TREE && c->target_surface_like)
             std::fprintf(stderr, "[symmicp dbg] pass %lld (packets): steps=%llu nodes+leaf candidates=%llu leaf candidates rejected=%llu points=%llu tie rescans=%llu overflows=%llu | packet ticks (10 ns): sum=%llu max=%llu\n",
                          (long long)c->st.passes, h[0], h[4], h[5], h[3], h[2], h[1], h[7], h[6]);
@@ -1130,8 +1187,7 @@ static constexpr uint32_t kLoopListLimit = 8192;
 static uint32_t loop_scan_limit(uint32_t n) { const uint32_t f = n / 256; return f < 8192u ? f : 8192u; }
 static bool batch_eligible(const symmicp_ctx *c)
 {
-    static const char *env = std::getenv("SYMMICP_HOST_LOOP");            // "1": never batch (A/B runs, tests)
-    if (env && env[0] == '1') return false;
+    if (c->sw.host_loop) return false;                                    // SYMMICP_HOST_LOOP=1: never batch (A/B runs, tests)
     if (c->cfg.host_loop) return false;
     if (c->external_exchange || c->shm.slots) return false;               // those exchanges run on the host
     if (c->timing == 2 || c->ix.dbg) return false;                        // per-kernel tables and debug counters: host loop
@@ -1143,8 +1199,8 @@ static bool batch_eligible(const symmicp_ctx *c)
     // TREE: the fused pass is for converged alignments: under 0.4 % of the pairs searched again, a short work list at most (stragglers
     // outside the overlap: real scans always have some)
     if (c->cfg.corr == SYMMICP_CORR_TREE)
-        return !incr && c->last_list_len >= 0 && c->last_list_len <= (std::getenv("SYMMICP_NO_LOOP_STRAGGLERS") ? 0ll : (long long)kLoopListLimit) && c->last_uncertified >= 0 &&
-               c->last_uncertified <= (long long)(loop_scan_limit(c->n_s_total) / (c->last_list_len > 0 ? 2 : 1)) && c->cert && !std::getenv("SYMMICP_NO_CERT");      // (the straggler stage costs two launches per pass)
+        return !incr && c->last_list_len >= 0 && c->last_list_len <= (c->sw.no_loop_stragglers ? 0ll : (long long)kLoopListLimit) && c->last_uncertified >= 0 &&
+               c->last_uncertified <= (long long)(loop_scan_limit(c->n_s_total) / (c->last_list_len > 0 ? 2 : 1)) && c->cert && !c->sw.no_cert;      // (the straggler stage costs two launches per pass)
     return false;
 }
 
@@ -1170,7 +1226,7 @@ static int run_batch(symmicp_ctx *c, int want, float *diffs_before, int *n_done,
     // stragglers: while passes leave a work list, every fused pass is followed by the walk over the list and the accumulation of its
     // pairs (two more launches per pass, ~10 us); decided per chunk of passes from the lists the previous chunk left.  Without the stage
     // a list that turns up stops the loop: the host redoes that pass and the next batch starts with the stage.
-    static const bool no_stage = std::getenv("SYMMICP_NO_LOOP_STRAGGLERS") != nullptr;      // A/B runs
+    const bool no_stage = c->sw.no_loop_stragglers;      // A/B runs
     bool stragglers = tree && c->last_list_len > 0 && !no_stage;
     lc.list_limit = kLoopListLimit;
     if (lc.max_iters > c->cfg.max_iters) lc.max_iters = c->cfg.max_iters;
@@ -1191,12 +1247,12 @@ static int run_batch(symmicp_ctx *c, int want, float *diffs_before, int *n_done,
     int blocks;
     bool vec4 = false;
     if (tree) {
-        static const int fb = std::getenv("SYMMICP_FUSED_BLOCKS") ? std::atoi(std::getenv("SYMMICP_FUSED_BLOCKS")) : 512;
+        const int fb = c->sw.fused_blocks;
         const int tiles = (int)((c->n_loc + kPassThreads - 1) / kPassThreads);
         blocks = tiles < fb ? tiles : fb;
     } else {
         vec4 = (c->n_loc % 4 == 0) && (c->n_t % 4 == 0) && (c->src_off % 4 == 0);
-        static const int id_cap = std::getenv("SYMMICP_ID_BLOCKS") ? std::atoi(std::getenv("SYMMICP_ID_BLOCKS")) : 2048;
+        const int id_cap = c->sw.id_blocks;
         const int nb = (int)(((vec4 ? c->n_loc / 4 : c->n_loc) + kPassThreads - 1) / kPassThreads);
         blocks = nb < id_cap ? (nb > 0 ? nb : 1) : id_cap;
     }
@@ -1236,7 +1292,7 @@ static int run_batch(symmicp_ctx *c, int want, float *diffs_before, int *n_done,
             }
             if (tree) {
                 launch_pass_fused(a, c->ix, c->wl, fused_blocks, c->stream);
-                if (stragglers) launch_loop_stragglers(a, c->ix, c->wl, kListBlocks, c->stream);
+                if (stragglers) launch_loop_stragglers(a, c->ix, c->wl, kListBlocks, c->sw.tune, c->stream);
             }
             else launch_pass_identity(a, c->tgt, blocks, vec4, c->stream);
             if (ev) { hipEventRecord(ev[4], c->stream); c->ev_used++; }
@@ -1316,7 +1372,7 @@ static int run_batch(symmicp_ctx *c, int want, float *diffs_before, int *n_done,
     *n_done = it1 - it0;
     *small_step = hl.reason == LOOP_DONE && hl.small_step != 0;
     if (tree && it1 > it0) c->last_uncertified = c->h_ring[it1 % symmicp_ctx::kRing].pad;
-    if (std::getenv("SYMMICP_DEBUG_HOST")) std::fprintf(stderr, "[symmicp host] batch: %d of %d passes on the device (%d enqueued), reason %d, %d with the straggler stage, list after %lld\n", it1 - it0, want, enq, hl.reason, n_stage, (long long)c->last_list_len);
+    if (c->sw.debug_host) std::fprintf(stderr, "[symmicp host] batch: %d of %d passes on the device (%d enqueued), reason %d, %d with the straggler stage, list after %lld\n", it1 - it0, want, enq, hl.reason, n_stage, (long long)c->last_list_len);
     if (hl.reason == LOOP_SLOW) c->host_passes_since_bailout = 1;      // one host pass, then look again
     if (hl.reason == LOOP_REDO_PASS || hl.reason == LOOP_HOST_SOLVE) {
         c->host_passes_since_bailout = 0;
@@ -1674,7 +1730,7 @@ int symmicp_comm_init_rank(symmicp_ctx *c, int nranks, int rank, const void *uid
     if (nranks < 1 || rank < 0 || rank >= nranks) return fail(c, SYMMICP_ERR_ARG, "bad rank/nranks");
     if (c->src0_block) return fail(c, SYMMICP_ERR_STATE, "attach the communicator before symmicp_set_source");
     // a 1-rank communicator is legal RCCL; it is only built on request (exercises the RCCL path on one GPU)
-    if (nranks == 1 && !std::getenv("SYMMICP_FORCE_COMM")) { c->nranks = 1; c->rank = 0; return SYMMICP_OK; }
+    if (nranks == 1 && !c->sw.force_comm) { c->nranks = 1; c->rank = 0; return SYMMICP_OK; }
     if (!uid) {
         // external exchange: shard like a rank of `nranks`, publish local records, the application sums them (symmicp_set_sums)
         if (nranks == 1) return fail(c, SYMMICP_ERR_ARG, "null unique id");
@@ -1776,6 +1832,10 @@ int symmicp_get_stats(symmicp_ctx *c, symmicp_stats *out)
     else b = (int64_t)c->n_loc * (48 + 4 + 4) + (int64_t)c->n_t * 12;
     if (incr) b += (int64_t)c->n_loc * 24;
     c->st.bytes_algorithmic_per_pass = b;
+    {
+        uint32_t fb = 0;
+        if (c->pkt_fallbacks && hipMemcpy(&fb, c->pkt_fallbacks, sizeof(fb), hipMemcpyDeviceToHost) == hipSuccess) c->st.packet_fallbacks = (int64_t)fb;
+    }
     *out = c->st;
     return SYMMICP_OK;
 }

@@ -204,9 +204,8 @@ struct PktCounters {
 
 template <bool CERT>
 __device__ __noinline__ void pkt_dfs(const float4 *__restrict__ onodes, const float4 *__restrict__ tq, const uint32_t *s_off, float4 (*stk)[2],
-                                     const float (*s_sb)[8], uint8_t *s_lvl, float px, float py, float pz, PktBest &b, float &thr, float pad, PktCounters &cn)
+                                     const float (*s_sb)[8], uint8_t *s_lvl, const int lane, float px, float py, float pz, PktBest &b, float &thr, float pad, PktCounters &cn)
 {
-    const int lane = threadIdx.x;
     const int sub = lane & 3, chl = lane >> 2;                          // lane 4c+g = (child c, sub-group g)
     const int bperm = (16 * sub + 15) * 4;                              // ds_bpermute address of sub-group g's last lane
     const float4 sblo = *reinterpret_cast<const float4 *>(&s_sb[sub][0]), sbhi = *reinterpret_cast<const float4 *>(&s_sb[sub][4]);
@@ -271,42 +270,74 @@ __device__ __noinline__ void pkt_dfs(const float4 *__restrict__ onodes, const fl
     }
 }
 
-// The packets are the queries [0, n) in order, 64 per packet: the first pass of an alignment (no previous pairs, every query is
-// searched from scratch).  Later passes have bounds from their previous pairs and mostly certificates; packets were measured
-// there too (previous pair as the bound, certificate test per lane) and lose to the cell scans of k_search_cells: 0.55 ms
-// against 0.35 ms for pass 2 of the 1M-point surface pair, 0.56 against 0.17 for pass 3 -- with tight bounds a packet is ten
-// nearly empty levels of round trips.
+// The packets are runs of up to 64 consecutive queries of the Morton-sorted share (PassArgs::pkt_tab, or 64 as they lie): the first pass
+// of an alignment (no previous pairs, every query is searched from scratch).  Later passes have bounds from their previous pairs and
+// mostly certificates; packets were measured there too (previous pair as the bound, certificate test per lane) and lose to the cell
+// scans of k_search_cells: 0.55 ms against 0.35 ms for pass 2 of the 1M-point surface pair, 0.56 against 0.17 for pass 3 -- with tight
+// bounds a packet is ten nearly empty levels of round trips.
+//
+// W waves per packet (one workgroup of 64 W threads).  A launch lasts at least as long as its slowest packet, and a rank's share of a
+// sharded run is a few thousand packets on 4096 wave slots: with one wave per packet the first pass did not divide by the number of
+// GPUs at all (0.57 ms at 1 GPU, 0.53 ms per rank at 8).  So the waves of a workgroup SHARE one packet: every wave holds all 64 queries
+// (one per lane) and its own running bests; the frontier of a level sits in LDS once, and the waves draw its steps (8 frontier nodes x 8
+// children) from a counter in LDS, scan the leaves their own steps turn up, and exchange bounds through 64 words of LDS (atomic min of
+// the d2 bits: a lane prunes with the best distance ANY wave has reached for its query).  At the end the per-wave bests are merged by
+// an LDS 64-bit atomic min on (d2 bits << 32 | original row): the lexicographic minimum brute force takes, whatever wave saw the point.
+// Every wave dives for a different query of the packet (quantiles of the wanting lanes), so the W dives leave every lane a bound from
+// a leaf near it.  W = 1 is the same code with wave-local barriers.
 constexpr int kFrontCap = 512;            // frontier nodes per level (two buffers of uint32 in LDS = the DFS stack's 4 KB); 256 / 384: 1.08 ms (more packets fall back to the depth-first walk), 1024: 0.90 ms (the widest packets sweep 1000-node levels: slower than falling back) against 0.66
 static_assert(2 * kFrontCap * sizeof(uint32_t) <= kPktStack * 2 * sizeof(float4), "frontier buffers alias the DFS stack");
+constexpr int kPktLevels = kMortonBits + 3;
+
+template <int W>
+__device__ __forceinline__ void pkt_sync()
+{
+    if (W == 1) __builtin_amdgcn_wave_barrier();      // (one wave: its LDS accesses are in order)
+    else __syncthreads();
+}
 
 #ifndef PKT_WAVES
 #define PKT_WAVES 4
 #endif
-template <bool DBG>
-__global__ __launch_bounds__(64, PKT_WAVES) void k_search_packet(PassArgs a, TargetIndex ix, uint32_t chunk)
+template <int W, bool DBG>
+__global__ __launch_bounds__(64 * W, PKT_WAVES) void k_search_packet(PassArgs a, TargetIndex ix, uint32_t chunk)
 {
     __shared__ float4 s_buf[kPktStack][2];         // BFS: two frontier buffers; DFS fallback: the stack
     __shared__ float s_sb[4][8];                   // bounding boxes of the four 16-query sub-groups
     __shared__ uint8_t s_lvl[kPktStack];           // DFS fallback: level of each stacked node
     __shared__ uint32_t s_off[kMortonBits + 2];
+    __shared__ uint32_t s_cnt[kPktLevels];         // frontier size per level
+    __shared__ uint32_t s_stp[kPktLevels];         // step dispenser per level (W > 1)
+    __shared__ uint32_t s_thr[64];                 // per query: d2 bits of the best distance any wave has reached (W > 1)
+    __shared__ unsigned long long s_key[64];       // per query: final merge (W > 1)
+    __shared__ uint32_t s_dive[W];                 // first point of the leaf each wave's dive scanned
     uint32_t (*fr)[kFrontCap] = reinterpret_cast<uint32_t (*)[kFrontCap]>(&s_buf[0][0]);
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int wave = (W == 1) ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const float inf = __int_as_float(0x7f800000);
-    if (lane < kMortonBits + 2) s_off[lane] = ix.olevel_off[lane];
+    if (threadIdx.x < kMortonBits + 2) s_off[threadIdx.x] = ix.olevel_off[threadIdx.x];
     __syncthreads();
     const uint32_t npk = a.pkt_tab ? a.pkt_count : (a.n + 63u) >> 6;
+    const uint32_t front_cap = min(a.pkt_front_cap ? a.pkt_front_cap : (uint32_t)kFrontCap, (uint32_t)kFrontCap);
     constexpr bool CERT = false;              // the first pass leaves no certificates (the cloud is about to move by its whole misalignment)
     const float pad = 0.0f;
     const float4 *__restrict__ tq = ix.tq;
     const float4 *__restrict__ onodes = ix.onodes;
     PktCounters cn = {0, 0, 0, 0, 0, 0, 0};
     for (uint32_t slot = xcd_remap_chunked(blockIdx.x, chunk); slot < npk; slot += gridDim.x) {
-        // a packet: `count` consecutive queries from `first` (the host's table: widest first), or 64 as they lie
+        // a packet: `count` consecutive queries from `first` (the table: widest first), or 64 as they lie
         uint32_t first = slot * 64u, count = 64u;
         if (a.pkt_tab) { const uint2 e = a.pkt_tab[slot]; first = e.x; count = e.y; }
         const uint32_t pk = slot;
         unsigned long long t_start = 0;
         if (DBG || ix.dbg_trace) t_start = __builtin_amdgcn_s_memrealtime();
+        const PktCounters cn0 = cn;
+        if (wave == 0) {
+            if (lane < kPktLevels) { s_cnt[lane] = 0; s_stp[lane] = 0; }
+            if (W > 1) { s_thr[lane] = 0x7f800000u; s_key[lane] = ~0ull; }
+            if (lane < W) s_dive[lane] = 0xFFFFFFFFu;
+        }
+        pkt_sync<W>();
         const uint32_t i = first + (uint32_t)lane;
         const bool active = (uint32_t)lane < count && i < a.n;
         float px = 0.f, py = 0.f, pz = 0.f;
@@ -318,14 +349,14 @@ __global__ __launch_bounds__(64, PKT_WAVES) void k_search_packet(PassArgs a, Tar
             px = xf_row(a.X.m + 0, x, y, z, 1.0f); py = xf_row(a.X.m + 4, x, y, z, 1.0f); pz = xf_row(a.X.m + 8, x, y, z, 1.0f);
             thr = ((px == px) & (py == py) & (pz == pz)) ? inf : -1.0f;      // NaN query: no pair
         }
-        const unsigned long long wants0 = __ballot(thr >= 0.0f);
+        const bool wants = thr >= 0.0f;     // (never changes: bounds only shrink towards 0)
+        const unsigned long long wants0 = __ballot(wants);
         uint32_t steps_pk = 0;
         bool ovf_pk = false;
-        if (wants0 != 0ull) {
+        if (wants0 != 0ull) {               // (the same in every wave of the workgroup: the barriers below are uniform)
             // ---- bounding boxes of the four sub-groups (lanes that want nothing do not stretch them): SGPRs, and LDS for the fallback
             float gl[4][3], gh[4][3];
             {
-                const bool wants = thr >= 0.0f;
                 const float lx = row_fmin(wants ? px : inf), ly = row_fmin(wants ? py : inf), lz = row_fmin(wants ? pz : inf);
                 const float hx = row_fmax(wants ? px : -inf), hy = row_fmax(wants ? py : -inf), hz = row_fmax(wants ? pz : -inf);
 #pragma unroll
@@ -333,7 +364,7 @@ __global__ __launch_bounds__(64, PKT_WAVES) void k_search_packet(PassArgs a, Tar
                     gl[g][0] = bcast(lx, 16 * g + 15); gl[g][1] = bcast(ly, 16 * g + 15); gl[g][2] = bcast(lz, 16 * g + 15);
                     gh[g][0] = bcast(hx, 16 * g + 15); gh[g][1] = bcast(hy, 16 * g + 15); gh[g][2] = bcast(hz, 16 * g + 15);
                 }
-                if ((lane & 15) == 15) {
+                if (wave == 0 && (lane & 15) == 15) {
                     float *sb = const_cast<float *>(s_sb[lane >> 4]);
                     sb[0] = lx; sb[1] = ly; sb[2] = lz; sb[3] = 0.f; sb[4] = hx; sb[5] = hy; sb[6] = hz; sb[7] = 0.f;
                 }
@@ -342,12 +373,16 @@ __global__ __launch_bounds__(64, PKT_WAVES) void k_search_packet(PassArgs a, Tar
             const uint32_t root_first = (uint32_t)__builtin_amdgcn_readfirstlane(__float_as_int(rootA.w));
             const uint32_t root_packed = (uint32_t)__builtin_amdgcn_readfirstlane(__float_as_int(rootB.w));
             bool done = false;
-            uint32_t dive_first = 0xFFFFFFFFu;          // first point of the leaf the dive scanned (a leaf is identified by it)
-            // ---- dive: a finite bound for every lane before the frontier is built (skipped when all lanes have one)
-            if (__ballot(thr == inf) != 0ull) {
-                const int mid = (wants0 >> 32) & 1ull ? 32 : (int)__ffsll((long long)wants0) - 1;
+            // ---- dive: a finite bound for every lane before the frontier is built.  Wave w dives for the query at quantile
+            // (2w + 1) / 2W of the wanting lanes, so that every lane gets a bound from a leaf near it
+            {
+                const int nw = __popcll(wants0);
+                int kth = ((2 * wave + 1) * nw) / (2 * W);            // 0-based rank among the wanting lanes
+                unsigned long long m = wants0;
+                while (kth-- > 0) m &= m - 1ull;
+                const int mid = (int)__ffsll((long long)m) - 1;
                 const float cx = bcast(px, mid), cy = bcast(py, mid), cz = bcast(pz, mid);
-                uint32_t packed = root_packed, first = root_first, level = 0;
+                uint32_t packed = root_packed, dfirst = root_first, level = 0;
                 while (oct_nch(packed) != 0u) {
                     const uint32_t nch = oct_nch(packed), cf = oct_cf(packed);
                     uint32_t key = 0xFFFFFFFFu;
@@ -360,42 +395,49 @@ __global__ __launch_bounds__(64, PKT_WAVES) void k_search_packet(PassArgs a, Tar
                     key = dpp_umin<0x111, 0xf>(key); key = dpp_umin<0x112, 0xf>(key); key = dpp_umin<0x114, 0xf>(key);      // lane 7: min of lanes 0..7
                     const int cmin = __builtin_amdgcn_readlane((int)key, 7) & 7;
                     packed = (uint32_t)__builtin_amdgcn_readlane(__float_as_int(cB.w), cmin);
-                    first = (uint32_t)__builtin_amdgcn_readlane(__float_as_int(cA.w), cmin);
+                    dfirst = (uint32_t)__builtin_amdgcn_readlane(__float_as_int(cA.w), cmin);
                     level++;
                     if (DBG) cn.steps++;
                 }
                 const uint32_t cnt = oct_cf(packed);
                 if (DBG) cn.points += cnt;
-                pkt_leaf_scalar<CERT>(tq, first, cnt, px, py, pz, b, cn.ties);
+                pkt_leaf_scalar<CERT>(tq, dfirst, cnt, px, py, pz, b, cn.ties);
                 thr = fminf(thr, pkt_threshold(b.d2, pad));
                 done = (level == 0);               // the root itself is a leaf: everything has been scanned
-                dive_first = first;                // the sweep below skips this leaf (a second scan would count its points as ties)
+                if (lane == 0) s_dive[wave] = dfirst;   // the sweep skips these leaves (a second scan would count their points as ties)
+                if (W > 1 && wants) atomicMin(&s_thr[lane], __float_as_uint(thr));
             }
             // ---- breadth-first sweep
-            uint32_t nf = 0;
+            if (!done && wave == 0 && lane == 0) { fr[0][0] = root_packed; s_cnt[0] = 1u; }
+            pkt_sync<W>();
+            uint32_t dive_w[W];
+#pragma unroll
+            for (int w = 0; w < W; w++) dive_w[w] = s_dive[w];
             int cur = 0;
-            if (!done && oct_nch(root_packed) != 0u) {
-                if (lane == 0) fr[0][0] = root_packed;
-                nf = 1;
-            } else if (!done) {
-                // the root is a leaf and there was no dive
-                pkt_leaf_scalar<CERT>(tq, root_first, oct_cf(root_packed), px, py, pz, b, cn.ties);
-                thr = fminf(thr, pkt_threshold(b.d2, pad));
-            }
-            __builtin_amdgcn_wave_barrier();
             bool overflow = false;
             uint32_t tg[4];
-            for (uint32_t level = 0; nf > 0 && !overflow; level++) {
-                uint32_t nn = 0;
+            for (uint32_t level = 0; !done; level++) {
+                const uint32_t nf = s_cnt[level];                       // (written before the barrier: the same in every wave)
+                if (nf == 0u) break;
+                if (nf > front_cap) { overflow = true; break; }
                 const uint32_t off_next = s_off[level + 1];
-                {
-                    const uint32_t tb = (thr >= 0.0f) ? __float_as_uint(thr) + 1u : 0u;   // 0: the lane wants nothing; else bits + 1 (a bound of 0 still admits gap 0)
-                    const uint32_t r = row_umax(tb);
-#pragma unroll
-                    for (int g = 0; g < 4; g++) tg[g] = (uint32_t)__builtin_amdgcn_readlane((int)r, 16 * g + 15);
-                }
-                for (uint32_t f0 = 0; f0 < nf; f0 += 8) {
+                uint32_t my_step = 0;
+                while (true) {
+                    uint32_t st = my_step++;
+                    if (W > 1) {
+                        if (lane == 0) st = atomicAdd(&s_stp[level], 1u);
+                        st = (uint32_t)__builtin_amdgcn_readfirstlane((int)st);
+                    }
+                    const uint32_t f0 = st * 8u;
+                    if (f0 >= nf) break;
                     if (DBG) { cn.steps++; steps_pk++; }
+                    if (W > 1 && wants) thr = __uint_as_float(min(__float_as_uint(thr), s_thr[lane]));      // what the other waves have reached
+                    {
+                        const uint32_t tb = wants ? __float_as_uint(thr) + 1u : 0u;   // 0: the lane wants nothing; else bits + 1 (a bound of 0 still admits gap 0)
+                        const uint32_t r = row_umax(tb);
+#pragma unroll
+                        for (int g = 0; g < 4; g++) tg[g] = (uint32_t)__builtin_amdgcn_readlane((int)r, 16 * g + 15);
+                    }
                     const uint32_t f = f0 + (uint32_t)(lane >> 3), c = (uint32_t)(lane & 7);
                     const uint32_t pkd = (f < nf) ? fr[cur][f] : 0u;
                     const bool valid = c < oct_nch(pkd);
@@ -420,9 +462,11 @@ __global__ __launch_bounds__(64, PKT_WAVES) void k_search_packet(PassArgs a, Tar
                     // internal survivors -> next frontier
                     const unsigned long long mI = __ballot(keepI);
                     if (mI) {
-                        const uint32_t slot = nn + __builtin_amdgcn_mbcnt_hi((uint32_t)(mI >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mI, 0u));
-                        if (keepI && slot < (uint32_t)kFrontCap) fr[cur ^ 1][slot] = cpk;
-                        nn += (uint32_t)__popcll(mI);
+                        uint32_t base = 0;
+                        if (lane == 0) base = atomicAdd(&s_cnt[level + 1], (uint32_t)__popcll(mI));
+                        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                        const uint32_t dst = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(mI >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mI, 0u));
+                        if (keepI && dst < front_cap) fr[cur ^ 1][dst] = cpk;
                     }
                     // leaf survivors: their lanes fetch the points (all leaves of the step at once), then one leaf at a time
                     unsigned long long mL = __ballot(keepL);
@@ -438,53 +482,66 @@ __global__ __launch_bounds__(64, PKT_WAVES) void k_search_packet(PassArgs a, Tar
                             const int src = (int)__ffsll((long long)mL) - 1;
                             mL &= mL - 1ull;
                             if (DBG) cn.leaves++;
-                            const uint32_t first = (uint32_t)__builtin_amdgcn_readlane(__float_as_int(cA.w), src);
-                            if (first == dive_first) continue;                                   // scanned by the dive already
+                            const uint32_t lfirst = (uint32_t)__builtin_amdgcn_readlane(__float_as_int(cA.w), src);
+                            bool dived = false;
+#pragma unroll
+                            for (int w = 0; w < W; w++) dived |= (lfirst == dive_w[w]);
+                            if (dived) continue;                                                 // scanned by a dive already
                             float4 lo, hi;
                             lo.x = bcast(cA.x, src); lo.y = bcast(cA.y, src); lo.z = bcast(cA.z, src);
                             hi.x = bcast(cB.x, src); hi.y = bcast(cB.y, src); hi.z = bcast(cB.z, src);
                             if (__ballot(boxdist2(px, py, pz, lo, hi) <= thr) == 0ull) { if (DBG) cn.rejected++; continue; }
                             const uint32_t cnt = oct_cf((uint32_t)__builtin_amdgcn_readlane((int)cpk, src));
                             if (DBG) cn.points += cnt;
-                            pkt_leaf_regs<CERT>(tq, pt, src, first, min(cnt, 8u), px, py, pz, b, cn.ties);
-                            if (cnt > 8u) pkt_leaf_scalar<CERT>(tq, first + 8u, cnt - 8u, px, py, pz, b, cn.ties);
+                            pkt_leaf_regs<CERT>(tq, pt, src, lfirst, min(cnt, 8u), px, py, pz, b, cn.ties);
+                            if (cnt > 8u) pkt_leaf_scalar<CERT>(tq, lfirst + 8u, cnt - 8u, px, py, pz, b, cn.ties);
                             thr = fminf(thr, pkt_threshold(b.d2, pad));
                             scanned = true;
                         }
-                        if (scanned) {
-                            const uint32_t tb = (thr >= 0.0f) ? __float_as_uint(thr) + 1u : 0u;
-                            const uint32_t r = row_umax(tb);
-#pragma unroll
-                            for (int g = 0; g < 4; g++) tg[g] = (uint32_t)__builtin_amdgcn_readlane((int)r, 16 * g + 15);
-                        }
+                        if (W > 1 && scanned && wants) thr = __uint_as_float(min(__float_as_uint(thr), atomicMin(&s_thr[lane], __float_as_uint(thr))));
                     }
                 }
-                if (nn > (uint32_t)kFrontCap) overflow = true;
-                nf = nn;
                 cur ^= 1;
-                __builtin_amdgcn_wave_barrier();
+                pkt_sync<W>();
             }
             if (overflow) {
-                // a frontier outgrew its LDS slot: finish depth-first from the root with the bounds reached so far (exact)
-                cn.overflow++;
+                // a frontier outgrew its LDS slot: wave 0 finishes depth-first from the root with the bounds reached so far (exact
+                // for any starting bounds; the other waves' bests join in the merge below)
                 ovf_pk = true;
-                pkt_dfs<CERT>(onodes, tq, s_off, s_buf, s_sb, s_lvl, px, py, pz, b, thr, pad, cn);
+                if (wave == 0) {
+                    cn.overflow++;
+                    if (lane == 0 && a.pkt_fallbacks) atomicAdd(a.pkt_fallbacks, 1u);
+                    if (W > 1 && wants) thr = __uint_as_float(min(__float_as_uint(thr), s_thr[lane]));
+                    // (copies: the call is not inlined, and state whose address escapes would live in scratch memory for the whole kernel --
+                    // every bound update of the sweep above a scratch store; that was most of the 217 MB the round-2 kernel wrote per launch)
+                    PktBest b2 = b;
+                    float thr2 = thr;
+                    PktCounters cn2 = {0, 0, 0, 0, 0, 0, 0};
+                    pkt_dfs<CERT>(onodes, tq, s_off, s_buf, s_sb, s_lvl, lane, px, py, pz, b2, thr2, pad, cn2);
+                    b = b2; thr = thr2;
+                    if (DBG) { cn.nodes += cn2.nodes; cn.leaves += cn2.leaves; cn.rejected += cn2.rejected; cn.points += cn2.points; cn.ties += cn2.ties; }
+                }
             }
         }
-        if (active) {
+        // ---- the answer: lexicographic minimum of (d2, original row) over the waves' bests
+        bool writer = (wave == 0);
+        if (W > 1) {
+            unsigned long long key = ~0ull;
+            if (active && b.pos >= 0) key = ((unsigned long long)__float_as_uint(b.d2) << 32) | (unsigned long long)(uint32_t)__float_as_int(tq[b.pos].w);
+            if (key != ~0ull) atomicMin(&s_key[lane], key);
+            __syncthreads();
+            const unsigned long long kmin = s_key[lane];
+            writer = (kmin == ~0ull) ? (wave == 0) : (key == kmin);      // (two waves holding the same point write the same values)
+            if (kmin == ~0ull) b.pos = -1;
+        }
+        if (active && writer) {
             a.pos_out[i] = b.pos;
             a.d2_out[i] = b.d2;
-            float L = 0.0f;
-            if (CERT && pad > 0.0f && b.pos >= 0) {
-                const float d1 = sqrtf(b.d2);
-                const float Lc = fminf(sqrtf(__uint_as_float(b.second)) * 0.999999f, (d1 + pad) * 0.99999f);
-                L = (Lc > d1 * 1.000001f) ? Lc : 0.0f;
-            }
-            a.cert[i] = make_float4(px, py, pz, L);
+            a.cert[i] = make_float4(px, py, pz, 0.0f);
             if (b.pos >= 0) store_pair_record(a, ix, i, b.pos);
             else a.pairrec[2 * (size_t)i + 1] = make_float4(0.f, 0.f, 0.f, 1.f);
         }
-        if (!DBG && ix.dbg_trace && lane == 0 && (size_t)pk < ((size_t)1 << 21)) {
+        if (!DBG && ix.dbg_trace && wave == 0 && lane == 0 && (size_t)pk < ((size_t)1 << 21)) {
             // timing-only trace of the production kernel (SYMMICP_DEBUG_TRACE without SYMMICP_DEBUG_COUNTERS): two stores per packet
             const unsigned long long dt = __builtin_amdgcn_s_memrealtime() - t_start;
             ix.dbg_trace[2 * (size_t)pk] = t_start;
@@ -492,13 +549,17 @@ __global__ __launch_bounds__(64, PKT_WAVES) void k_search_packet(PassArgs a, Tar
         }
         if (DBG && lane == 0) {
             const unsigned long long dt = __builtin_amdgcn_s_memrealtime() - t_start;      // 100 MHz ticks
-            atomicMax(ix.dbg + 6, dt);
-            atomicAdd(ix.dbg + 7, dt);
-            if (ix.dbg_trace && (size_t)pk < ((size_t)1 << 21)) {
-                ix.dbg_trace[2 * (size_t)pk] = t_start;
-                ix.dbg_trace[2 * (size_t)pk + 1] = (dt << 32) | ((unsigned long long)(steps_pk & 0xFFFFFFu) << 8) | (unsigned long long)(ovf_pk ? 1u : 0u);
+            if (wave == 0) { atomicMax(ix.dbg + 6, dt); atomicAdd(ix.dbg + 7, dt); }
+            if (ix.dbg_trace && (size_t)pk < ((size_t)1 << 18)) {
+                // instrumented build: 8 words per packet -- start, (ticks, first query), then per wave (steps, leaves scanned, points, tie rescans) since the packet began
+                unsigned long long *tr = ix.dbg_trace + 8 * (size_t)pk;
+                if (wave == 0) { tr[0] = t_start; tr[1] = (dt << 32) | (unsigned long long)((first << 1) | (ovf_pk ? 1u : 0u)); }
+                tr[2 + wave] = ((unsigned long long)(steps_pk & 0xFFFFu) << 48) | ((unsigned long long)((cn.leaves - cn.rejected - cn0.leaves + cn0.rejected) & 0xFFFFu) << 32) |
+                               ((unsigned long long)((cn.points - cn0.points) & 0xFFFFFFu) << 8) | (unsigned long long)((cn.ties - cn0.ties) & 0xFFu);
+                if (wave == 0) tr[6] = ((unsigned long long)(cn.nodes - cn0.nodes) << 32) | (unsigned long long)(cn.leaves - cn0.leaves);
             }
         }
+        if (W > 1) __syncthreads();          // (the next packet resets what this one's merge has just read)
     }
     if (DBG && lane == 0) {
         atomicAdd(ix.dbg + 0, cn.steps);
@@ -518,7 +579,13 @@ __global__ __launch_bounds__(64, PKT_WAVES) void k_search_packet(PassArgs a, Tar
 // between consecutive queries longer than kJumpFactor x the block's own scale (the smallest radius of its four groups of 16).
 // Per run: (first, count) into `runs`, key = descending squared radius (top key_bits bits), value = its index in `runs`.
 constexpr float kJumpFactor = 5.0f;        // (3: 0.60 ms, 5: 0.55, 6: 0.56, 8-10: 0.59, never: 0.655 on the 1M surface pair)
-constexpr int kMaxRunsPerBlock = 4;
+// A block whose four groups of 16 ALL straddle jumps has no small group to take its scale from, and with three cuts at most a block with
+// more jumps kept runs hundreds of point spacings wide: the first blocks of a rank's share (a thin strip of the cloud, crossed by the
+// Morton curve again and again) were such -- two packets per share of the 8-way split 1M pair overflowed their frontier and finished
+// depth-first in 450-500 us, which was the whole first pass of those ranks.  So the scale is also bounded by the block's MEDIAN step
+// between consecutive queries (kMedianSteps of them: a compact group of 16 is 4-8 median steps across), and a block may be cut 7 times.
+constexpr float kMedianSteps = 6.0f;
+constexpr int kMaxRunsPerBlock = 8;
 
 __global__ __launch_bounds__(64) void k_packet_runs(CloudSoA src, uint32_t n, float jump_factor, uint2 *__restrict__ runs, uint32_t *__restrict__ keys,
                                                     uint32_t *__restrict__ vals, uint32_t *__restrict__ count, int key_bits)
@@ -539,9 +606,25 @@ __global__ __launch_bounds__(64) void k_packet_runs(CloudSoA src, uint32_t n, fl
     float scale2 = (cnt >= 8.f) ? r16 : __int_as_float(0x7f800000);        // (a nearly empty tail group says nothing)
     scale2 = fminf(scale2, __shfl_xor(scale2, 16, 64));
     scale2 = fminf(scale2, __shfl_xor(scale2, 32, 64));
-    // jumps: steps from the previous query of the block longer than the factor allows
+    // steps from the previous query of the block, and their median (rank counting over the wave; ties by lane)
     const float px = __shfl_up(x, 1, 64), py = __shfl_up(y, 1, 64), pz = __shfl_up(z, 1, 64);
-    bool jump = active && lane > 0 && jump_factor > 0.f && dist2(x, y, z, px, py, pz) > jump_factor * jump_factor * scale2;
+    const bool has_step = active && lane > 0;
+    const float step2 = has_step ? dist2(x, y, z, px, py, pz) : __int_as_float(0x7f800000);
+    {
+        const int nsteps = __popcll(__ballot(has_step));
+        int rank = 0;
+        for (int j = 1; j < 64; j++) {
+            const float o = __shfl(step2, j, 64);
+            rank += (o < step2 || (o == step2 && j < lane)) ? 1 : 0;
+        }
+        const unsigned long long mm = __ballot(has_step && rank == (nsteps - 1) / 2);
+        if (nsteps >= 8 && mm) {
+            const float med2 = __shfl(step2, (int)__ffsll((long long)mm) - 1, 64);
+            scale2 = fminf(scale2, kMedianSteps * kMedianSteps * med2);
+        }
+    }
+    // jumps: steps longer than the factor allows
+    bool jump = has_step && jump_factor > 0.f && step2 > jump_factor * jump_factor * scale2;
     unsigned long long jm = __ballot(jump);
     // keep the first kMaxRunsPerBlock - 1 jumps
     for (int k = 0; k < kMaxRunsPerBlock - 1 && jm; k++) jm &= jm - 1;       // jm: the jumps beyond the limit ...
@@ -555,7 +638,7 @@ __global__ __launch_bounds__(64) void k_packet_runs(CloudSoA src, uint32_t n, fl
     const int end = above ? (int)__ffsll((long long)above) - 1 : nact;       // exclusive
     // radius of the run: centroid, then the farthest member (segmented by run: lanes exchange only within [start, end))
     float cx = 0.f, cy = 0.f, cz = 0.f, r2 = 0.f;
-    for (unsigned long long m = cuts; m; m &= m - 1) {                       // (<= 4 runs)
+    for (unsigned long long m = cuts; m; m &= m - 1) {                       // (<= kMaxRunsPerBlock runs)
         const int s0 = (int)__ffsll((long long)m) - 1;
         const bool mine = active && start == s0;
         float ax = mine ? x : 0.f, ay = mine ? y : 0.f, az = mine ? z : 0.f, ac = mine ? 1.f : 0.f;
@@ -599,18 +682,37 @@ void launch_packet_table(const uint32_t *order, const uint2 *runs, uint32_t npk,
 // first pass of an alignment: no previous pairs, every query is searched -- packets over the whole (sorted) share
 void launch_accumulate(const PassArgs &a, const float4 *tn, int blocks, hipStream_t s);
 
+// Waves per packet.  One wave per packet has the best throughput (no barriers, no redundant dives) as long as the launch has several
+// rounds of packets per wave slot to balance its tail with (longest first); a launch with few packets per slot -- a rank's share of a
+// sharded run, a small cloud -- lasts as long as its slowest packets, and those run W times faster on W waves.
+static uint32_t pick_packet_waves(uint32_t npk)
+{
+    constexpr uint32_t kWaveSlots = 256u * 4u * PKT_WAVES;      // CUs x SIMDs x waves per SIMD of this kernel
+    if (npk >= 4u * kWaveSlots) return 1u;
+    if (npk >= 2u * kWaveSlots) return 2u;
+    return 4u;
+}
+
+template <int W>
+static void launch_packets(const PassArgs &a, const TargetIndex &ix, uint32_t nbp, uint32_t chunk, uint32_t lds_pad, hipStream_t s)
+{
+    if (ix.dbg) hipLaunchKernelGGL((k_search_packet<W, true>), dim3(nbp), dim3(64 * W), lds_pad, s, a, ix, chunk);
+    else hipLaunchKernelGGL((k_search_packet<W, false>), dim3(nbp), dim3(64 * W), lds_pad, s, a, ix, chunk);
+}
+
 void launch_pass_tree_first(const PassArgs &a_in, const TargetIndex &ix, const WorkLists &, int acc_blocks, hipStream_t s, hipEvent_t *ev)
 {
     PassArgs a = a_in;
     a.refresh_records = 1;
     const uint32_t npk = a.pkt_tab ? a.pkt_count : (a.n + 63u) / 64u;
-    static const uint32_t chunk = getenv("SYMMICP_PACKET_CHUNK") ? (uint32_t)atol(getenv("SYMMICP_PACKET_CHUNK")) : 64u;      // packets per chunk (xcd_remap_chunked)
+    const uint32_t chunk = a.pkt_chunk ? a.pkt_chunk : 64u;      // packets per chunk (xcd_remap_chunked)
     const uint32_t nbp = ((npk + 8u * chunk - 1u) / (8u * chunk)) * (8u * chunk);
     if (ev) { hipEventRecord(ev[0], s); hipEventRecord(ev[1], s); hipEventRecord(ev[2], s); }
-    static const uint32_t lds_pad = getenv("SYMMICP_PACKET_LDS_PAD") ? (uint32_t)atol(getenv("SYMMICP_PACKET_LDS_PAD")) : 0u;      // occupancy experiments
+    const uint32_t w = a.pkt_waves ? a.pkt_waves : pick_packet_waves(npk);
     if (!npk) { /* empty share */ }
-    else if (ix.dbg) hipLaunchKernelGGL((k_search_packet<true>), dim3(nbp), dim3(64), lds_pad, s, a, ix, chunk);
-    else hipLaunchKernelGGL((k_search_packet<false>), dim3(nbp), dim3(64), lds_pad, s, a, ix, chunk);
+    else if (w >= 4u) launch_packets<4>(a, ix, nbp, chunk, a.pkt_lds_pad, s);
+    else if (w >= 2u) launch_packets<2>(a, ix, nbp, chunk, a.pkt_lds_pad, s);
+    else launch_packets<1>(a, ix, nbp, chunk, a.pkt_lds_pad, s);
     if (ev) hipEventRecord(ev[3], s);
     launch_accumulate(a, ix.tn, acc_blocks, s);
     if (ev) hipEventRecord(ev[4], s);

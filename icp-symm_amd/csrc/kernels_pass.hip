@@ -1527,11 +1527,11 @@ uint32_t walk_blocks_full(const WorkLists &wl)
 // and repairs the pass otherwise); 2 = the repair: walk and accumulate
 // compact_blocks > 0: the search runs as k_pass_fused<false> on that many blocks (sparse scans), else as k_search_cells
 void launch_pass_tree_split(const PassArgs &a_in, const TargetIndex &ix, const WorkLists &wl, int acc_blocks, uint32_t walk_blocks,
-                            int stage, int compact_blocks, hipStream_t s, hipEvent_t *ev)
+                            int stage, int compact_blocks, const PassTuning &tune, hipStream_t s, hipEvent_t *ev)
 {
     PassArgs a = a_in;
     a.refresh_records = (stage != 1) ? 1 : 0;      // a stage-1 pass may still be repaired: its accumulate must not settle stale copies
-    static const uint32_t wave_mode_max = getenv("SYMMICP_WAVE_MODE_MAX") ? (uint32_t)atol(getenv("SYMMICP_WAVE_MODE_MAX")) : 20000u;   // work lists longer than this use one thread per query (the 48k-entry list after the first move of the 1M surface pair: 115 -> 85 us)
+    const uint32_t wave_mode_max = tune.wave_mode_max;
     // all shard counters are zero here: cleared by the previous pass's final reduce
     const uint32_t nb = (a.n + kPassThreads - 1) / kPassThreads;
     const uint32_t nbp = ((nb + 7u) / 8u) * 8u;
@@ -1539,7 +1539,7 @@ void launch_pass_tree_split(const PassArgs &a_in, const TargetIndex &ix, const W
     if (stage != 2 && nbp) {      // (nbp == 0: a rank whose share is empty)
         if (compact_blocks > 0) hipLaunchKernelGGL(k_pass_fused<false>, dim3(min((uint32_t)compact_blocks, nbp)), dim3(kPassThreads), 0, s, a, ix, wl);
         else {
-            static const uint32_t chunk = getenv("SYMMICP_CELLS_CHUNK") ? (uint32_t)atol(getenv("SYMMICP_CELLS_CHUNK")) : 16u;      // tiles per chunk
+            const uint32_t chunk = tune.cells_chunk ? tune.cells_chunk : 16u;      // tiles per chunk
             const uint32_t nbc = ((nb + 8u * chunk - 1u) / (8u * chunk)) * (8u * chunk);
             if (a.make_hood) hipLaunchKernelGGL(k_search_cells<true>, dim3(nbc), dim3(kPassThreads), 0, s, a, ix, wl, chunk);
             else hipLaunchKernelGGL(k_search_cells<false>, dim3(nbc), dim3(kPassThreads), 0, s, a, ix, wl, chunk);
@@ -1554,7 +1554,7 @@ void launch_pass_tree_split(const PassArgs &a_in, const TargetIndex &ix, const W
         // clouds below the threshold, e.g. 1M points over 8 ranks)
         const uint32_t wmm = a.pos_prev ? wave_mode_max : 0u;
         if (a.budget_walk) {
-            static const uint32_t budget = getenv("SYMMICP_WALK_BUDGET") ? (uint32_t)atol(getenv("SYMMICP_WALK_BUDGET")) : 160u;
+            const uint32_t budget = tune.walk_budget;
             hipLaunchKernelGGL(k_search_walk<true>, dim3(walk_blocks), dim3(kWalkThreads), 0, s, a, ix, wl, wl.work, wmm, budget);
             // the retry list: wave regime forced (every entry carries a bound now), no budget
             hipLaunchKernelGGL(k_search_walk<false>, dim3(8192), dim3(kWalkThreads), 0, s, a, ix, wl, wl.retry, 0xFFFFFFFFu, 0xFFFFFFFFu);
@@ -1584,10 +1584,10 @@ void launch_pass_fused(const PassArgs &a, const TargetIndex &ix, const WorkLists
     hipLaunchKernelGGL(k_pass_fused<true>, dim3(blocks), dim3(kPassThreads), 0, s, a, ix, wl);
 }
 
-void launch_loop_stragglers(const PassArgs &a, const TargetIndex &ix, const WorkLists &wl, int list_blocks, hipStream_t s)
+void launch_loop_stragglers(const PassArgs &a, const TargetIndex &ix, const WorkLists &wl, int list_blocks, const PassTuning &tune, hipStream_t s)
 {
     // (short lists: the wave-per-entry regime; anything above the threshold strides one thread per entry over this grid)
-    static const uint32_t wave_mode_max = getenv("SYMMICP_WAVE_MODE_MAX") ? (uint32_t)atol(getenv("SYMMICP_WAVE_MODE_MAX")) : 20000u;
+    const uint32_t wave_mode_max = tune.wave_mode_max;
     hipLaunchKernelGGL(k_search_walk<false>, dim3(512), dim3(kWalkThreads), 0, s, a, ix, wl, wl.work, wave_mode_max, 0xFFFFFFFFu);
     hipLaunchKernelGGL(k_accumulate_list, dim3(list_blocks), dim3(kPassThreads), 0, s, a, ix.tn, wl.work);
 }

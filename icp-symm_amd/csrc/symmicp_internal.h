@@ -148,6 +148,17 @@ struct PassArgs {
     uint32_t partial_cols, partial_col0;   // partial records: columns in all (0: the grid's size) and this launch's first column
     const uint2 *pkt_tab;               // first pass (packets): (first query, count <= 64) per packet in start order (null: 64 as they lie)
     uint32_t pkt_count;
+    uint32_t pkt_waves;                 // first pass: waves that share one packet (1, 2 or 4; 0: the launcher decides from the packet count)
+    uint32_t pkt_front_cap;             // ... frontier capacity per level (0: kFrontCap; smaller values force the depth-first fallback: tests)
+    uint32_t *pkt_fallbacks;            // ... counts the packets that finished depth-first (may be null)
+    uint32_t pkt_chunk, pkt_lds_pad;    // ... packets per XCD chunk (0: 64); extra dynamic LDS per workgroup (occupancy experiments)
+};
+
+// host-side launch tuning of the tree passes (environment switches, read once by the engine)
+struct PassTuning {
+    uint32_t wave_mode_max = 20000u;    // work lists longer than this use one thread per query (the 48k-entry list after the first move of the 1M surface pair: 115 -> 85 us)
+    uint32_t cells_chunk = 16u;         // tiles per XCD chunk of k_search_cells
+    uint32_t walk_budget = 160u;        // node visits of the budgeted walk (sharded first passes on volume-like targets)
 };
 
 // ---- kernel launchers (kernels.hip) ---------------------------------------
@@ -158,7 +169,7 @@ void launch_pass_indexed(const PassArgs &a, const float4 *tn /* pair records */,
 // stage: 0 = cells, walk, accumulate; 1 = cells, accumulate (walk skipped); 2 = walk, accumulate (repair of a stage-1 pass)
 // compact_blocks > 0: the cell search runs as the streaming, compacting kernel (k_pass_fused<false>) on that many blocks
 void launch_pass_tree_split(const PassArgs &a, const TargetIndex &ix, const WorkLists &wl, int acc_blocks, uint32_t walk_blocks,
-                            int stage, int compact_blocks, hipStream_t s, hipEvent_t *ev);
+                            int stage, int compact_blocks, const PassTuning &tune, hipStream_t s, hipEvent_t *ev);
 void launch_pass_tree_first(const PassArgs &a, const TargetIndex &ix, const WorkLists &wl, int acc_blocks, hipStream_t s, hipEvent_t *ev);
 uint32_t walk_blocks_full(const WorkLists &wl);
 uint32_t shard_capacity(uint32_t n_points);
@@ -168,7 +179,7 @@ void launch_final_reduce(const double *partials, int blocks, double *out_dev, do
 // fused pass of a converged alignment (k_pass_fused) and the device-side end of a pass (k_reduce_solve): see kernels_pass.hip
 void launch_pass_fused(const PassArgs &a, const TargetIndex &ix, const WorkLists &wl, int blocks, hipStream_t s);
 // device-driven loop, straggler stage behind a fused pass: the work list through the tree walk, then its pairs into `list_blocks` more partial columns
-void launch_loop_stragglers(const PassArgs &a, const TargetIndex &ix, const WorkLists &wl, int list_blocks, hipStream_t s);
+void launch_loop_stragglers(const PassArgs &a, const TargetIndex &ix, const WorkLists &wl, int list_blocks, const PassTuning &tune, hipStream_t s);
 // mode 0: reduce + check + solve (single GPU); 1: the record is already in out_dev (after the all-reduce); 2: solve only (start of a batch)
 void launch_reduce_solve(const double *partials, int blocks, double *out_dev, int mode, LoopState *loop, LoopConfig cfg, LoopRecord *ring, int ring_len,
                          uint32_t *counters_to_clear, hipStream_t s);

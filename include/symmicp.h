@@ -228,6 +228,9 @@ typedef struct {
     /* passes that ran inside device-driven runs of iterations (symmicp_align), and those of them that carried the straggler stage
      * (tree walk over a non-empty work list inside the run) */
     int64_t loop_passes, loop_straggler_passes;
+    /* first passes run as 64-query packets (kernels_packet.hip): packets whose breadth-first frontier outgrew its LDS slot and that
+     * finished depth-first instead (exact either way; 0 on the BASELINE workloads), since symmicp_create */
+    int64_t packet_fallbacks;
 } symmicp_stats;
 int symmicp_get_stats(symmicp_ctx *ctx, symmicp_stats *out);
 int symmicp_reset_stats(symmicp_ctx *ctx);
