@@ -1372,6 +1372,10 @@ static int run_batch(symmicp_ctx *c, int want, float *diffs_before, int *n_done,
     *n_done = it1 - it0;
     *small_step = hl.reason == LOOP_DONE && hl.small_step != 0;
     if (tree && it1 > it0) c->last_uncertified = c->h_ring[it1 % symmicp_ctx::kRing].pad;
+    if (c->sw.debug_host && it1 - it0 >= 2) {      // (a library built with -DRS_STAMPS leaves k_reduce_solve's phase durations in the spare slots of each record)
+        const double *q = c->h_ring[(it1 - 1) % symmicp_ctx::kRing].sums;
+        if (q[37] != 0.0) std::fprintf(stderr, "[symmicp host] k_reduce_solve stamps of pass %d: load + reduce %.2f us (loop state there after %.2f us), bookkeeping + solve %.2f us, publish %.2f us\n", it1 - 1, std::floor(q[37]) * 0.01, (q[37] - std::floor(q[37])) * 1e4 * 0.01, q[38] * 0.01, q[39] * 0.01);
+    }
     if (c->sw.debug_host) std::fprintf(stderr, "[symmicp host] batch: %d of %d passes on the device (%d enqueued), reason %d, %d with the straggler stage, list after %lld\n", it1 - it0, want, enq, hl.reason, n_stage, (long long)c->last_list_len);
     if (hl.reason == LOOP_SLOW) c->host_passes_since_bailout = 1;      // one host pass, then look again
     if (hl.reason == LOOP_REDO_PASS || hl.reason == LOOP_HOST_SOLVE) {
@@ -1448,6 +1452,72 @@ int symmicp_step(symmicp_ctx *c, symmicp_iter_result *out)
     return SYMMICP_OK;
 }
 
+// ---- the reference's result block (myicp.cpp:146-149) --------------------------------------------------------------
+// `std::cout << matrix` with Eigen's default IOFormat: every coefficient through the stream's default float formatting (precision 6:
+// what "%g" prints), right-aligned to the widest coefficient OF THAT MATRIX, columns separated by one space, rows by a newline
+// (Eigen/src/Core/IO.h, print_matrix; published behaviour -- Eigen is not under /root/reference).
+static size_t append_eigen(std::string &out, const float *m, int rows, int cols, int stride)
+{
+    char cell[16][32];
+    size_t width = 0;
+    for (int r = 0; r < rows; r++)
+        for (int c = 0; c < cols; c++) {
+            std::snprintf(cell[r * cols + c], sizeof(cell[0]), "%g", (double)m[r * stride + c]);
+            width = std::max(width, std::strlen(cell[r * cols + c]));
+        }
+    for (int r = 0; r < rows; r++) {
+        for (int c = 0; c < cols; c++) {
+            if (c) out += ' ';
+            const size_t len = std::strlen(cell[r * cols + c]);
+            out.append(width - len, ' ');
+            out += cell[r * cols + c];
+        }
+        out += '\n';                 // (rows are separated by "\n"; the reference ends each matrix with std::endl)
+    }
+    return width;
+}
+
+// Affine3f::rotation() is the orthogonal polar factor of the linear part (Eigen computes it as U V^T of a JacobiSVD in fp32): here by
+// Newton's iteration R <- (R + R^-T) / 2 in fp64, which converges to the same matrix; for the rigid transforms of this path it differs
+// from the linear part in the last bit or two.  A singular linear part is printed as it is.
+static void polar_rotation(const float X[16], float R[9])
+{
+    double A[3][3];
+    for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) A[r][c] = X[4 * r + c];
+    for (int it = 0; it < 100; it++) {
+        const double det = A[0][0] * (A[1][1] * A[2][2] - A[1][2] * A[2][1]) - A[0][1] * (A[1][0] * A[2][2] - A[1][2] * A[2][0]) + A[0][2] * (A[1][0] * A[2][1] - A[1][1] * A[2][0]);
+        if (!(std::fabs(det) > 1e-300) || !std::isfinite(det)) break;
+        double inv_t[3][3];          // A^-T = cofactor matrix / det
+        inv_t[0][0] = (A[1][1] * A[2][2] - A[1][2] * A[2][1]) / det; inv_t[0][1] = (A[1][2] * A[2][0] - A[1][0] * A[2][2]) / det; inv_t[0][2] = (A[1][0] * A[2][1] - A[1][1] * A[2][0]) / det;
+        inv_t[1][0] = (A[0][2] * A[2][1] - A[0][1] * A[2][2]) / det; inv_t[1][1] = (A[0][0] * A[2][2] - A[0][2] * A[2][0]) / det; inv_t[1][2] = (A[0][1] * A[2][0] - A[0][0] * A[2][1]) / det;
+        inv_t[2][0] = (A[0][1] * A[1][2] - A[0][2] * A[1][1]) / det; inv_t[2][1] = (A[0][2] * A[1][0] - A[0][0] * A[1][2]) / det; inv_t[2][2] = (A[0][0] * A[1][1] - A[0][1] * A[1][0]) / det;
+        double change = 0.0;
+        for (int r = 0; r < 3; r++)
+            for (int c = 0; c < 3; c++) { const double v = 0.5 * (A[r][c] + inv_t[r][c]); change = std::max(change, std::fabs(v - A[r][c])); A[r][c] = v; }
+        if (change < 1e-15) break;
+    }
+    for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) R[3 * r + c] = std::isfinite(A[r][c]) ? (float)A[r][c] : X[4 * r + c];
+}
+
+size_t symmicp_format_result(const float transform16[16], char *buf, size_t cap)
+{
+    if (!transform16) return 0;
+    std::string out = "Result transform:\n";
+    append_eigen(out, transform16, 4, 4, 4);
+    out += "  rotation:\n";
+    float R[9];
+    polar_rotation(transform16, R);
+    append_eigen(out, R, 3, 3, 3);
+    out += "  translation:\n";
+    append_eigen(out, transform16 + 3, 3, 1, 4);
+    if (buf && cap) {
+        const size_t n = std::min(out.size(), cap - 1);
+        std::memcpy(buf, out.data(), n);
+        buf[n] = 0;
+    }
+    return out.size();
+}
+
 int symmicp_align(symmicp_ctx *c, const float *guess16, symmicp_result *out)
 {
     if (!c || !out) return SYMMICP_ERR_ARG;
@@ -1502,12 +1572,9 @@ int symmicp_align(symmicp_ctx *c, const float *guess16, symmicp_result *out)
     std::memcpy(out->transform, c->X, sizeof(float) * 16);
     out->seconds_total = now_s() - t0;
     if (c->cfg.verbose) {                                           // myicp.cpp:146-149
-        const float *X = c->X;
-        std::printf("Result transform:\n");
-        for (int r = 0; r < 4; r++) std::printf("%g %g %g %g\n", X[4 * r], X[4 * r + 1], X[4 * r + 2], X[4 * r + 3]);
-        std::printf("  rotation:\n");
-        for (int r = 0; r < 3; r++) std::printf("%g %g %g\n", X[4 * r], X[4 * r + 1], X[4 * r + 2]);
-        std::printf("  translation:\n%g\n%g\n%g\n", X[3], X[7], X[11]);
+        char buf[1024];
+        symmicp_format_result(c->X, buf, sizeof(buf));
+        std::fputs(buf, stdout);
     }
     return st;
 }

@@ -164,9 +164,11 @@ __device__ __forceinline__ float bcast(float v, int src_lane)
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src_lane));
 }
 
-// the first m (<= 8) points of the leaf sit in the registers pt[0..7] of lane `src` (wave-uniform): broadcast and test
+// the first m (<= 8) points of the leaf sit in the registers pt[0..7] of lane `src` (wave-uniform): broadcast and test.  Only the coordinates
+// are kept in registers (24 instead of 32: the kernel's occupancy is register-bound); the rows a tie needs are read from memory (rare)
+struct Pt3 { float x, y, z; };
 template <bool CERT>
-__device__ __forceinline__ void pkt_leaf_regs(const float4 *__restrict__ tq, const float4 (&pt)[8], int src, uint32_t first, uint32_t m, float px,
+__device__ __forceinline__ void pkt_leaf_regs(const float4 *__restrict__ tq, const Pt3 (&pt)[8], int src, uint32_t first, uint32_t m, float px,
                                               float py, float pz, PktBest &b, unsigned long long &c_tie)
 {
     int32_t slot = 8;
@@ -183,13 +185,11 @@ __device__ __forceinline__ void pkt_leaf_regs(const float4 *__restrict__ tq, con
     if (tie != 0ull) {
         c_tie++;
         int32_t brow = (b.pos >= 0) ? __float_as_int(tq[b.pos].w) : 0x7fffffff;
-#pragma unroll
-        for (int k = 0; k < 8; k++) {
-            if ((uint32_t)k < m) {
-                const int32_t row = __builtin_amdgcn_readlane(__float_as_int(pt[k].w), src);
-                const float d2 = dist2(px, py, pz, bcast(pt[k].x, src), bcast(pt[k].y, src), bcast(pt[k].z, src));
-                if (d2 == b.d2 && row < brow) { brow = row; b.pos = (int32_t)first + k; }
-            }
+        for (uint32_t k = 0; k < m; k++) {
+            const float4 q = tq[first + k];                    // (wave-uniform address)
+            const float d2 = dist2(px, py, pz, q.x, q.y, q.z);
+            const int32_t row = __float_as_int(q.w);
+            if (d2 == b.d2 && row < brow) { brow = row; b.pos = (int32_t)(first + k); }
         }
     }
 }
@@ -471,11 +471,11 @@ __global__ __launch_bounds__(64 * W, PKT_WAVES) void k_search_packet(PassArgs a,
                     // leaf survivors: their lanes fetch the points (all leaves of the step at once), then one leaf at a time
                     unsigned long long mL = __ballot(keepL);
                     if (mL) {
-                        float4 pt[8];
+                        Pt3 pt[8];
                         if (keepL) {
                             const float4 *__restrict__ lp = tq + (uint32_t)__float_as_int(cA.w);
 #pragma unroll
-                            for (int k = 0; k < 8; k++) pt[k] = lp[k];                    // (tq is padded by 8 entries)
+                            for (int k = 0; k < 8; k++) pt[k] = *reinterpret_cast<const Pt3 *>(lp + k);      // 12-byte loads (tq is padded by 8 entries)
                         }
                         bool scanned = false;
                         while (mL) {
@@ -610,25 +610,22 @@ __global__ __launch_bounds__(64) void k_packet_runs(CloudSoA src, uint32_t n, fl
     const float px = __shfl_up(x, 1, 64), py = __shfl_up(y, 1, 64), pz = __shfl_up(z, 1, 64);
     const bool has_step = active && lane > 0;
     const float step2 = has_step ? dist2(x, y, z, px, py, pz) : __int_as_float(0x7f800000);
+    const int nsteps = __popcll(__ballot(has_step));
+    int rank = 0;                          // steps of the block shorter than this lane's
+    for (int j = 1; j < 64; j++) {
+        const float o = __shfl(step2, j, 64);
+        rank += (o < step2 || (o == step2 && j < lane)) ? 1 : 0;
+    }
     {
-        const int nsteps = __popcll(__ballot(has_step));
-        int rank = 0;
-        for (int j = 1; j < 64; j++) {
-            const float o = __shfl(step2, j, 64);
-            rank += (o < step2 || (o == step2 && j < lane)) ? 1 : 0;
-        }
         const unsigned long long mm = __ballot(has_step && rank == (nsteps - 1) / 2);
-        if (nsteps >= 8 && mm) {
+        if (nsteps >= 3 && mm) {
             const float med2 = __shfl(step2, (int)__ffsll((long long)mm) - 1, 64);
             scale2 = fminf(scale2, kMedianSteps * kMedianSteps * med2);
         }
     }
-    // jumps: steps longer than the factor allows
-    bool jump = has_step && jump_factor > 0.f && step2 > jump_factor * jump_factor * scale2;
-    unsigned long long jm = __ballot(jump);
-    // keep the first kMaxRunsPerBlock - 1 jumps
-    for (int k = 0; k < kMaxRunsPerBlock - 1 && jm; k++) jm &= jm - 1;       // jm: the jumps beyond the limit ...
-    const unsigned long long cuts = (__ballot(jump) & ~jm) | 1ull;            // ... removed; bit j set: a run starts at lane j
+    // jumps: steps longer than the factor allows; of more than kMaxRunsPerBlock - 1 the longest are cut
+    const bool jump = has_step && jump_factor > 0.f && step2 > jump_factor * jump_factor * scale2 && rank >= nsteps - (kMaxRunsPerBlock - 1);
+    const unsigned long long cuts = __ballot(jump) | 1ull;                    // bit j set: a run starts at lane j
     const unsigned long long act = __ballot(active);
     // this lane's run: from the last cut at or below it to the next cut (or the end of the active lanes)
     const unsigned long long below = cuts & ((2ull << lane) - 1ull);

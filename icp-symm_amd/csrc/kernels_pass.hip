@@ -104,7 +104,9 @@ __device__ __forceinline__ double wave_sum_to_lane63(double x)
 }
 
 // block reduction: DPP wave sums, then LDS across the 4 waves; fixed order -> deterministic.
-// record k of block b lands at partials[k * nblocks + b] (transposed: the final reduce reads it coalesced)
+// record k of block b lands at partials[b * kNSum + k]: one contiguous 320-byte burst per block.  (Round 2 stored it transposed,
+// [k][block], so that the reduce could read along the blocks: 40 scattered 8-byte stores per block into lines shared with up to 15
+// other blocks -- on other XCDs, i.e. other L2s -- and a reduce whose load phase alone took 5.9 us of k_reduce_solve's 11.5.)
 __device__ __forceinline__ void acc_block_reduce_store(Acc &a, double *partials, uint32_t nblocks, uint32_t col)
 {
     __shared__ double red[(kPassThreads / 64) * kNSum];
@@ -121,8 +123,9 @@ __device__ __forceinline__ void acc_block_reduce_store(Acc &a, double *partials,
 #pragma unroll
             for (int w = 0; w < kPassThreads / 64; w++) s += red[w * kNSum + threadIdx.x];
         }
-        partials[(size_t)threadIdx.x * nblocks + col] = s;
+        partials[(size_t)col * kNSum + threadIdx.x] = s;
     }
+    (void)nblocks;
 }
 
 __device__ __forceinline__ void acc_block_reduce_store(Acc &a, double *partials, uint32_t nblocks) { acc_block_reduce_store(a, partials, nblocks, blockIdx.x); }
@@ -791,7 +794,7 @@ __global__ __launch_bounds__(kPassThreads) void k_search_cells(PassArgs a, Targe
 // separate kernels).  The transform comes from the device-resident loop state when there is one (a.loop): passes can be
 // enqueued back to back without the host (k_reduce_solve writes the next transform); a stopped loop returns at once.
 // ---------------------------------------------------------------------------
-constexpr int kFusedList = 1024;
+constexpr int kFusedList = 2048;      // (>= two tiles of the fused pass: a tile is 1024 points there)
 
 __device__ __forceinline__ void fused_accumulate(Acc &acc, const PassArgs &a, const Affine &X, float nx, float ny, float nz, float px, float py, float pz,
                                                  const float4 &q, const float4 &nq, float d2)
@@ -808,6 +811,9 @@ __device__ __forceinline__ void fused_accumulate(Acc &acc, const PassArgs &a, co
 #ifndef COMPACT_WAVES
 #define COMPACT_WAVES 5
 #endif
+#ifndef FUSED_PPT
+#define FUSED_PPT 1u      // points per thread of the fused pass's streaming loop
+#endif
 // ACC = true: the fused pass described above.  ACC = false: only the search part (stream + scan), for the passes of an alignment
 // that is still settling: the separate k_search_cells lets every block of 256 queries pay the latency of the whole scan machinery
 // for the dozen of them that need it; here a block streams several tiles and scans the failures 256 at a time (the walk and
@@ -815,19 +821,53 @@ __device__ __forceinline__ void fused_accumulate(Acc &acc, const PassArgs &a, co
 template <bool ACC>
 __global__ __launch_bounds__(kPassThreads, ACC ? FUSED_WAVES : COMPACT_WAVES) void k_pass_fused(PassArgs a, TargetIndex ix, WorkLists wl)
 {
-    if (a.loop && a.loop->stop) return;
-    __shared__ uint32_t s_list[kFusedList];
+    constexpr int kList = ACC ? kFusedList : kFusedList / 2;      // (the search-only form keeps 5 workgroups per CU: its tile is 256 points)
+    __shared__ uint32_t s_list[kList];
     __shared__ uint32_t s_cnt, s_total;
-    const Affine X = a.loop ? a.loop->Xapply : a.X;
+    // device-driven loop: stop flag and transform come from device memory, written by the kernel just before this one -- a cold round trip.
+    // They are requested here and first LOOKED AT behind the first tile's loads (which do not depend on them): one round trip, not two
+    // (behind the barrier: scalar loads and LDS stores share a counter, and the barrier waits for it)
     Acc acc;
     if (ACC) acc_zero(acc);
     if (threadIdx.x == 0) { s_cnt = 0; s_total = 0; }
     __syncthreads();
+    int stop = 0;
+    Affine X = a.X;
+    if (a.loop) { stop = a.loop->stop; X = a.loop->Xapply; }
     const uint32_t shard = blockIdx.x & (kShards - 1);
 
-    // the listed queries: exact scan 256 at a time, then (ACC) the ones that now have a pair are accumulated from their fresh record copy
+    // the listed queries (their single certificate has failed): (ACC) first the neighbourhood certificate -- the winner is a member of the set
+    // the last scan kept: decided among 8 gathers, accumulated on the spot -- then the exact scan of the others 256 at a time, then (ACC) those
+    // that now have a pair are accumulated from their fresh record copy.  (The neighbourhood test used to sit in the streaming loop; with 4
+    // points per thread there it is 4 inlined copies and the kernel spills.)
     auto flush = [&]() {
         const uint32_t cnt = s_cnt;
+        if (ACC && a.certk) {
+            for (uint32_t base = 0; base < cnt; base += kPassThreads) {
+                const uint32_t e = base + threadIdx.x;
+                if (e >= cnt) continue;
+                const uint32_t i = s_list[e];
+                const float4 ce = a.cert[i];
+                if (!(__float_as_uint(ce.w) & 1u)) continue;
+                const float4 q = a.pairrec[2 * (size_t)i], nq = a.pairrec[2 * (size_t)i + 1];
+                const int32_t pk = a.pos_prev[i];
+                if (nq.w != 0.0f || (uint32_t)pk >= ix.n) continue;
+                const float x = a.in.x[i], y = a.in.y[i], z = a.in.z[i];
+                const float px = xf_row(X.m + 0, x, y, z, 1.0f), py = xf_row(X.m + 4, x, y, z, 1.0f), pz = xf_row(X.m + 8, x, y, z, 1.0f);
+                const float d2 = dist2(px, py, pz, q.x, q.y, q.z);
+                if (!(d2 <= __int_as_float(0x7f800000))) continue;
+                int32_t pw; float d2w;
+                if (hood_test(a, ix, i, px, py, pz, dist2(px, py, pz, ce.x, ce.y, ce.z), pk, d2, __float_as_int(q.w), pw, d2w)) {
+                    float4 qw = q, nqw = nq;
+                    if (pw != pk) { qw = ix.tn[2 * (size_t)pw]; nqw = ix.tn[2 * (size_t)pw + 1]; }
+                    a.d2_out[i] = d2w;
+                    const float nx = a.in.nx[i], ny = a.in.ny[i], nz = a.in.nz[i];
+                    fused_accumulate(acc, a, X, nx, ny, nz, px, py, pz, qw, nqw, d2w);
+                    s_list[e] = 0xFFFFFFFFu;                       // settled (an idle lane of the scan below)
+                }
+            }
+            __syncthreads();
+        }
         for (uint32_t base = 0; base < cnt; base += kPassThreads) {
             const uint32_t e = base + threadIdx.x;
             cells_tile<true>(a, ix, wl, X, e < cnt ? s_list[e] : 0xFFFFFFFFu, shard, true);
@@ -838,6 +878,7 @@ __global__ __launch_bounds__(kPassThreads, ACC ? FUSED_WAVES : COMPACT_WAVES) vo
                 const uint32_t e = base + threadIdx.x;
                 if (e >= cnt) continue;
                 const uint32_t i = s_list[e];
+                if (i == 0xFFFFFFFFu) continue;                        // settled by its neighbourhood above
                 const float4 q = a.pairrec[2 * (size_t)i], nq = a.pairrec[2 * (size_t)i + 1];
                 if (nq.w != 0.0f) continue;                            // no target at all, or handed to the walk
                 const float x = a.in.x[i], y = a.in.y[i], z = a.in.z[i];
@@ -851,65 +892,79 @@ __global__ __launch_bounds__(kPassThreads, ACC ? FUSED_WAVES : COMPACT_WAVES) vo
         __syncthreads();
     };
 
-    const uint32_t tiles = (a.n + kPassThreads - 1) / kPassThreads;
+    // A tile = kPpt x 256 consecutive points; a thread takes the points tid, tid + 256, ... of its tile (every load coalesced).  ACC: 4 points
+    // per thread -- all 4 x (6 columns + 2 x 16 B record copy + 16 B certificate) = 288 B per lane are requested before the first is
+    // used: with one point per thread (76 B per lane in flight, 2 waves per SIMD) the pass moved its bytes at 3.0 TB/s (25 us at 1M points)
+    constexpr uint32_t kPpt = ACC ? FUSED_PPT : 1u;
+    constexpr uint32_t kTilePts = kPpt * kPassThreads;
+    const uint32_t tiles = (a.n + kTilePts - 1) / kTilePts;
     // ACC: one contiguous eighth of the tiles per XCD (uniform work, best locality); search only: chunks of 16 tiles (the regions of a
     // cloud differ in cost: xcd_remap_chunked)
     constexpr uint32_t kTileChunk = 16;
     const uint32_t tiles_p = ACC ? ((tiles + 7u) / 8u) * 8u : ((tiles + 8u * kTileChunk - 1u) / (8u * kTileChunk)) * (8u * kTileChunk);
-    constexpr int kCheck = ACC ? 3 : 1;
+    constexpr int kCheck = ACC ? 1 : 1;
     int since = 0;
     // ---- stream (tile numbers are dealt so that each XCD works on one contiguous part of the sorted source)
     for (uint32_t t = blockIdx.x; t < tiles_p; t += gridDim.x) {
-        const uint32_t i = (ACC ? xcd_remap(t, tiles_p) : xcd_remap_chunked(t, kTileChunk)) * kPassThreads + threadIdx.x;
-        if (i < a.n) {
-            // one round trip: everything the common case (certified pair) needs.  (Measured and dropped: fetching the next tile before
-            // working on this one -- no gain, the pass already moves its 76 B per point at ~3.2 TB/s; letting the last block to finish
-            // reduce and solve in place of k_reduce_solve -- the device-scope fences it needs cost every block an L2 write-back, 79 us
-            // per pass instead of 27 + 12.)
-            const float x = a.in.x[i], y = a.in.y[i], z = a.in.z[i];
-            float nx = 0.f, ny = 0.f, nz = 0.f;
-            float4 q, nq = make_float4(0.f, 0.f, 0.f, 2.0f);
-            int32_t pa = -1;
-            if (ACC) {
-                nx = a.in.nx[i]; ny = a.in.ny[i]; nz = a.in.nz[i];
-                q = a.pairrec[2 * (size_t)i]; nq = a.pairrec[2 * (size_t)i + 1];      // a fresh copy (w = 0) has the bits of tq[prev]
-            } else {
-                pa = a.pos_prev[i];
-                if ((uint32_t)pa < ix.n) { q = ix.tq[pa]; nq.w = 0.0f; }
-            }
-            const float4 ce = a.cert[i];
-            const float px = xf_row(X.m + 0, x, y, z, 1.0f), py = xf_row(X.m + 4, x, y, z, 1.0f), pz = xf_row(X.m + 8, x, y, z, 1.0f);
-            bool certified = false;
-            float d2 = 0.0f;
-            float4 qw = q, nqw = nq;                               // the pair that is accumulated
-            if (nq.w == 0.0f) {
-                d2 = dist2(px, py, pz, q.x, q.y, q.z);
-                const float m2 = dist2(px, py, pz, ce.x, ce.y, ce.z);
-                certified = (__builtin_amdgcn_sqrtf(d2) + __builtin_amdgcn_sqrtf(m2)) * 1.000002f < ce.w;          // cells_tile, phase 1
-                if (!certified && d2 <= __int_as_float(0x7f800000) && (__float_as_uint(ce.w) & 1u) && a.certk) {
-                    // the neighbourhood certificate: the winner is a member of the set the last scan kept
-                    if (ACC) pa = a.pos_prev[i];
-                    int32_t pw; float d2w;
-                    if ((uint32_t)pa < ix.n && hood_test(a, ix, i, px, py, pz, m2, pa, d2, __float_as_int(q.w), pw, d2w)) {
-                        certified = true;
-                        if (ACC && pw != pa) { qw = ix.tn[2 * (size_t)pw]; nqw = ix.tn[2 * (size_t)pw + 1]; }
-                        d2 = d2w;
-                    }
+        const uint32_t i0 = (ACC ? xcd_remap(t, tiles_p) : xcd_remap_chunked(t, kTileChunk)) * kTilePts + threadIdx.x;
+        // one round trip: everything the common case (certified pair) needs.  (Measured and dropped: letting the last block to finish
+        // reduce and solve in place of k_reduce_solve with device-scope fences -- every block then waits for an L2 write-back, 79 us
+        // per pass instead of 27 + 12.)
+        float x[kPpt], y[kPpt], z[kPpt], nx[kPpt], ny[kPpt], nz[kPpt];
+        float4 q[kPpt], nq[kPpt], ce[kPpt];
+        int32_t pa[kPpt];
+#pragma unroll
+        for (uint32_t k = 0; k < kPpt; k++) {
+            const uint32_t i = i0 + k * kPassThreads;
+            nq[k] = make_float4(0.f, 0.f, 0.f, 2.0f);
+            pa[k] = -1;
+            if (i < a.n) {
+                x[k] = a.in.x[i]; y[k] = a.in.y[i]; z[k] = a.in.z[i];
+                if (ACC) {
+                    nx[k] = a.in.nx[i]; ny[k] = a.in.ny[i]; nz[k] = a.in.nz[i];
+                    q[k] = a.pairrec[2 * (size_t)i]; nq[k] = a.pairrec[2 * (size_t)i + 1];      // a fresh copy (w = 0) has the bits of tq[prev]
+                } else {
+                    pa[k] = a.pos_prev[i];
+                    if ((uint32_t)pa[k] < ix.n) { q[k] = ix.tq[pa[k]]; nq[k].w = 0.0f; }
                 }
-            }
-            if (certified) {
-                a.d2_out[i] = d2;                                  // refreshed distance of the (possibly changed) pair
-                if (ACC) fused_accumulate(acc, a, X, nx, ny, nz, px, py, pz, qw, nqw, d2);
-            } else {
-                s_list[atomicAdd(&s_cnt, 1u)] = i;                 // (room for a whole tile: see the flush below)
+                ce[k] = a.cert[i];
             }
         }
-        // room for kCheck more tiles?  (uniform: everyone reads s_cnt after the barrier; the fused pass of a converged alignment has
-        // next to no failures and pays the barrier only every third tile)
+        if (stop) return;                 // (uniform; nothing has been written yet)
+#pragma unroll
+        for (uint32_t k = 0; k < kPpt; k++) {
+            const uint32_t i = i0 + k * kPassThreads;
+            if (i < a.n) {
+                const float px = xf_row(X.m + 0, x[k], y[k], z[k], 1.0f), py = xf_row(X.m + 4, x[k], y[k], z[k], 1.0f), pz = xf_row(X.m + 8, x[k], y[k], z[k], 1.0f);
+                bool certified = false;
+                float d2 = 0.0f;
+                if (nq[k].w == 0.0f) {
+                    d2 = dist2(px, py, pz, q[k].x, q[k].y, q[k].z);
+                    const float m2 = dist2(px, py, pz, ce[k].x, ce[k].y, ce[k].z);
+                    certified = (__builtin_amdgcn_sqrtf(d2) + __builtin_amdgcn_sqrtf(m2)) * 1.000002f < ce[k].w;          // cells_tile, phase 1
+                    if (!ACC && !certified && d2 <= __int_as_float(0x7f800000) && (__float_as_uint(ce[k].w) & 1u) && a.certk) {
+                        // the neighbourhood certificate: the winner is a member of the set the last scan kept (ACC: in the flush)
+                        const int32_t pk = pa[k];
+                        int32_t pw; float d2w;
+                        if ((uint32_t)pk < ix.n && hood_test(a, ix, i, px, py, pz, m2, pk, d2, __float_as_int(q[k].w), pw, d2w)) {
+                            certified = true;
+                            d2 = d2w;
+                        }
+                    }
+                }
+                if (certified) {
+                    a.d2_out[i] = d2;                                  // refreshed distance of the (possibly changed) pair
+                    if (ACC) fused_accumulate(acc, a, X, nx[k], ny[k], nz[k], px, py, pz, q[k], nq[k], d2);
+                } else {
+                    s_list[atomicAdd(&s_cnt, 1u)] = i;                 // (room for a whole tile: see the flush below)
+                }
+            }
+        }
+        // room for another tile?  (uniform: everyone reads s_cnt after the barrier)
         if (++since == kCheck) {
             since = 0;
             __syncthreads();
-            if (s_cnt > (uint32_t)(kFusedList - kCheck * kPassThreads)) flush();
+            if (s_cnt > (uint32_t)(kList - kCheck * (int)kTilePts)) flush();
         }
     }
     __syncthreads();
@@ -1210,8 +1265,8 @@ __device__ __forceinline__ void read_list_words(const uint32_t *cnt, int t, uint
 }
 
 // ---------------------------------------------------------------------------
-// final reduce: partials[40][nblocks] -> 40 doubles.  One 256-thread block per sum: coalesced
-// independent loads, then a fixed pairwise tree in LDS (deterministic).  Writes the device record
+// final reduce: partials[nblocks][40] -> 40 doubles.  One 256-thread block per sum: independent loads
+// (8 bytes of every block's record: latency-bound, not bandwidth-bound), then a fixed pairwise tree in LDS (deterministic).  Writes the device record
 // and, when given, a host-mapped copy (single-GPU read-back without a memcpy).
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_final_reduce(const double *__restrict__ partials, int nblocks,
@@ -1220,9 +1275,8 @@ __global__ __launch_bounds__(256) void k_final_reduce(const double *__restrict__
 {
     __shared__ double red[256];
     const int k = blockIdx.x, t = threadIdx.x;
-    const double *row = partials + (size_t)k * nblocks;
     double s = 0.0;
-    for (int j = t; j < nblocks; j += 256) s += row[j];
+    for (int j = t; j < nblocks; j += 256) s += partials[(size_t)j * kNSum + k];
     red[t] = s;
     __syncthreads();
 #pragma unroll
@@ -1293,44 +1347,48 @@ __global__ __launch_bounds__(512) void k_reduce_solve(const double *__restrict__
     __shared__ double s_sum[kNSum];
     __shared__ uint32_t s_len, s_unc;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+#ifdef RS_STAMPS
+    const unsigned long long ts0 = __builtin_amdgcn_s_memrealtime();
+#endif
     // This block is one chain of dependent steps behind a kernel boundary: everything it reads from memory is requested up front, in one
     // round trip (the loop state, the work list's counters, the partial records), instead of one round trip per step (12 -> ~9 us).
     const LoopState ls = *loop;                       // (wave-uniform: scalar loads)
-    double v[5];
     uint32_t cw0 = 0, cw1 = 0, cw2 = 0;               // wave 0: the shard counters (see read_list_words)
     const bool want_counters = !solve_only && REDUCE && counters_to_clear && t < 64;
     if (want_counters) {
         cw0 = counters_to_clear[t * kShardStride]; cw1 = counters_to_clear[t * kShardStride + 1];
         cw2 = (t < 2) ? counters_to_clear[t * kShards * kShardStride + 2] : 0u;
     }
-    if (!solve_only && REDUCE) {
-        // wave w sums rows w, w + 8, ... (5 rows); all of a wave's loads are issued before the first sum
+    // lane k < 40 of wave w sums slot k of the records of blocks w, w + 8, w + 16, ...: every load is one contiguous 320-byte record,
+    // nothing has to cross lanes, the order is fixed.  All loads of a thread are issued before its first sum.
+    __shared__ double s_part[8][kNSum];
+    double accw = 0.0;
+    if (!solve_only && REDUCE && lane < kNSum) {
+        if (nblocks <= 512) {
+            double c[64];
 #pragma unroll
-        for (int r = 0; r < 5; r++) {
-            const double *row = partials + (size_t)(wave + 8 * r) * nblocks;
-            double acc0 = 0.0;
-            if (nblocks <= 512) {
-                double c[8];
+            for (int j = 0; j < 64; j++) { const int b = wave + 8 * j; c[j] = (b < nblocks) ? partials[(size_t)b * kNSum + lane] : 0.0; }
 #pragma unroll
-                for (int j = 0; j < 8; j++) c[j] = (lane + 64 * j < nblocks) ? row[lane + 64 * j] : 0.0;
-#pragma unroll
-                for (int j = 0; j < 8; j++) acc0 += c[j];
-            } else {
-                for (int j = lane; j < nblocks; j += 64) acc0 += row[j];
-            }
-            v[r] = acc0;
+            for (int j = 0; j < 64; j++) accw += c[j];
+        } else {
+            for (int b = wave; b < nblocks; b += 8) accw += partials[(size_t)b * kNSum + lane];
         }
     }
     double rec = 0.0;
     if ((solve_only || !REDUCE) && t < kNSum) rec = out_dev[t];
     if (ls.stop) return;
+#ifdef RS_STAMPS
+    const unsigned long long tsA = __builtin_amdgcn_s_memrealtime();
+#endif
     if (t == 0) { s_len = 0; s_unc = 0; }
     if (!solve_only && REDUCE) {
+        if (lane < kNSum) s_part[wave][lane] = accw;
+        __syncthreads();
+        if (t < kNSum) {
+            double x = 0.0;
 #pragma unroll
-        for (int r = 0; r < 5; r++) {
-            const double x = wave_sum_to_lane63(v[r]);
-            const int k = wave + 8 * r;
-            if (lane == 63) s_sum[k] = (k < kNAcc) ? x : 0.0;
+            for (int w = 0; w < 8; w++) x += s_part[w][t];
+            s_sum[t] = (t < kNAcc) ? x : 0.0;
         }
     } else if (t < kNSum) s_sum[t] = rec;
     __syncthreads();
@@ -1353,22 +1411,30 @@ __global__ __launch_bounds__(512) void k_reduce_solve(const double *__restrict__
             s_unc = (uint32_t)s_sum[kNSum - 2];
         }
     }
-    if (t != 0) return;
+    __syncthreads();
+#ifdef RS_STAMPS
+    const unsigned long long ts1 = __builtin_amdgcn_s_memrealtime();
+#endif
+    // (every thread takes the same decisions from the same words; the record is written by 40 lanes at once, not by one lane 40 times)
     int it = ls.iters;
     if (!solve_only) {
+        const uint32_t len = s_len, unc = s_unc;
         // a non-empty work list: handled by the straggler stage of this very pass, or the pass has to be redone by the host; dropped
         // appends (0xFFFFFFFF) always go back
-        if (cfg.tree && s_len > 0u && (!cfg.walk_in_loop || s_len == 0xFFFFFFFFu)) { loop->stop = 1; loop->reason = LOOP_REDO_PASS; return; }
+        if (cfg.tree && len > 0u && (!cfg.walk_in_loop || len == 0xFFFFFFFFu)) { if (t == 0) { loop->stop = 1; loop->reason = LOOP_REDO_PASS; } return; }
         it += 1;                                                        // this pass is complete
-        loop->iters = it;
         LoopRecord &r = ring[it % ring_len];
-        for (int k = 0; k < kNSum; k++) { const double v = (k >= kNAcc) ? 0.0 : s_sum[k]; r.sums[k] = v; if (REDUCE) out_dev[k] = v; }
-        r.solved = 0;
-        r.pad = (int32_t)s_unc;
-        r.list_len = (int32_t)s_len; r.reserved = 0;
+        if (t < kNSum) { const double v = (t >= kNAcc) ? 0.0 : s_sum[t]; r.sums[t] = v; if (REDUCE) out_dev[t] = v; }
+        if (t == 0) {
+            loop->iters = it;
+            r.solved = 0;
+            r.pad = (int32_t)unc;
+            r.list_len = (int32_t)len; r.reserved = 0;
+        }
         // many pairs had to be searched again (the cloud moved): the separate kernels do that faster; this pass is complete
-        if (cfg.tree && (s_unc > cfg.uncertified_limit || (cfg.walk_in_loop && s_len > cfg.list_limit))) { loop->stop = 1; loop->reason = LOOP_SLOW; return; }
+        if (cfg.tree && (unc > cfg.uncertified_limit || (cfg.walk_in_loop && len > cfg.list_limit))) { if (t == 0) { loop->stop = 1; loop->reason = LOOP_SLOW; } return; }
     }
+    if (t != 0) return;
     // ---- myicp.cpp:123
     const float diff = (float)s_sum[33];
     if (ls.small_step || !((cfg.fixed_iters || diff > cfg.diff_threshold) && it < cfg.max_iters)) {
@@ -1382,6 +1448,9 @@ __global__ __launch_bounds__(512) void k_reduce_solve(const double *__restrict__
     const int st = (cfg.mode == SYMMICP_MODE_QUIRKS) ? solve::solve_quirks(S, pbar, qbar, av, tv, &rc, Xi, false)
                                                       : solve::solve_paper(S, cfg.pivot, pbar, qbar, av, tv, &rc, Xi, false);
     if (st != SYMMICP_OK || !(rc > 1e-6f)) { loop->stop = 1; loop->reason = LOOP_HOST_SOLVE; return; }
+#ifdef RS_STAMPS
+    const unsigned long long ts2 = __builtin_amdgcn_s_memrealtime();
+#endif
     float Xn[16];
     solve::mat4_mul(Xi, ls.X, Xn);                                   // myicp.cpp:138
     for (int k = 0; k < 16; k++) loop->X[k] = Xn[k];
@@ -1391,6 +1460,9 @@ __global__ __launch_bounds__(512) void k_reduce_solve(const double *__restrict__
     LoopRecord &r = ring[it % ring_len];
     for (int k = 0; k < 16; k++) { r.increment[k] = Xi[k]; r.X[k] = Xn[k]; }
     r.rcond = rc; r.status = st; r.solved = 1;
+#ifdef RS_STAMPS
+    r.sums[37] = (double)(ts1 - ts0) + 1e-4 * (double)(tsA - ts0); r.sums[38] = (double)(ts2 - ts1); r.sums[39] = (double)(__builtin_amdgcn_s_memrealtime() - ts2);      // 10 ns ticks: load + reduce, bookkeeping + solve, publish
+#endif
     if (cfg.eps_rotation > 0.f && cfg.eps_translation > 0.f && !cfg.fixed_iters) {
         // convergence on the increment (engine.cpp, symmicp_align): the pass that applies this increment still runs
         const double tr = ((double)Xi[0] + Xi[5] + Xi[10] - 1.0) * 0.5;

@@ -71,7 +71,7 @@ KERNEL_SLOTS = ["k_search_cells", "(gap)", "k_search_walk", "k_accumulate", "k_f
 EXPORTS = [
     "symmicp_config_default", "symmicp_create", "symmicp_destroy", "symmicp_last_error", "symmicp_set_config",
     "symmicp_version", "symmicp_set_source", "symmicp_set_target", "symmicp_align", "symmicp_begin", "symmicp_step",
-    "symmicp_get_transform", "symmicp_get_pivot", "symmicp_get_correspondences", "symmicp_get_source",
+    "symmicp_get_transform", "symmicp_format_result", "symmicp_get_pivot", "symmicp_get_correspondences", "symmicp_get_source",
     "symmicp_local_source_count", "symmicp_local_source_offset", "symmicp_get_certificates", "symmicp_solve", "symmicp_comm_get_unique_id",
     "symmicp_comm_init_rank", "symmicp_set_sums", "symmicp_comm_init_shm", "symmicp_shard_range", "symmicp_get_stats", "symmicp_reset_stats", "symmicp_enable_timing",
     "symmicp_pcd_read", "symmicp_pcd_write", "symmicp_estimate_normals", "symmicp_ctx_estimate_normals",
@@ -118,6 +118,8 @@ def lib():
     L.symmicp_step.argtypes = [vp, C.POINTER(IterResult)]
     L.symmicp_get_transform.argtypes = [vp, fp]
     L.symmicp_get_pivot.argtypes = [vp, fp]
+    L.symmicp_format_result.argtypes = [fp, C.c_char_p, C.c_size_t]
+    L.symmicp_format_result.restype = C.c_size_t
     L.symmicp_get_correspondences.argtypes = [vp, C.POINTER(C.c_int32), fp, C.c_size_t]
     L.symmicp_get_source.argtypes = [vp, fp, fp, C.c_size_t]
     L.symmicp_local_source_count.argtypes = [vp]
@@ -202,6 +204,15 @@ def solve(mode, sums, pivot=None):
         pv = _fptr(pivot)
     st = lib().symmicp_solve(mode, C.byref(S), pv, _fptr(pb), _fptr(qb), _fptr(a), _fptr(t), C.byref(rc), _fptr(X))
     return st, pb, qb, a, t, rc.value, X.reshape(4, 4)
+
+
+def format_result(transform):
+    """The reference's result block for a 4x4 (myicp.cpp:146-149, Eigen's default IOFormat); needs no GPU."""
+    X = np.ascontiguousarray(np.asarray(transform, np.float32).reshape(16))
+    n = lib().symmicp_format_result(_fptr(X), None, 0)
+    buf = C.create_string_buffer(n + 1)
+    lib().symmicp_format_result(_fptr(X), buf, n + 1)
+    return buf.value.decode()
 
 
 def estimate_normals(xyz, k=10, viewpoint=(0.0, 0.0, 0.0), device=-1):

@@ -152,6 +152,11 @@ int symmicp_begin(symmicp_ctx *ctx, const float *guess16, symmicp_iter_result *o
  * (func.cpp:104-121) -> new pairs + sums + diff (myicp.cpp:128-141). */
 int symmicp_step(symmicp_ctx *ctx, symmicp_iter_result *out);
 int symmicp_get_transform(const symmicp_ctx *ctx, float out16[16]);           /* myicp.cpp:147 */
+/* The result block exactly as the reference prints it (myicp.cpp:146-149: "Result transform:" + transform.matrix(), "  rotation:" +
+ * transform.rotation(), "  translation:" + transform.translation(), each through Eigen's default IOFormat: precision 6, every
+ * coefficient right-aligned to the widest one of its matrix, one space between columns).  Writes at most cap - 1 characters and a
+ * terminating 0; returns the length of the whole text (buf may be NULL to query it).  symmicp_align prints this when cfg.verbose. */
+size_t symmicp_format_result(const float transform16[16], char *buf, size_t cap);
 int symmicp_get_pivot(const symmicp_ctx *ctx, float out3[3]);
 /* current pairs in ORIGINAL numbering: idx[i] = target row paired with source row i
  * (rows of this rank's share; -1 = rejected), d2[i] = squared distance. Either may be NULL. */

@@ -531,6 +531,15 @@ def test_cpp_driver_prints_the_reference_lines(cat, tmp_path):
     # normals come from the GPU k-NN PCA here, from the oracle's in the golden file: same to fp noise
     assert np.abs(T - cat["golden"]["quirks_identity_T"]).max() < 5e-4
     assert "  rotation:" in out and "  translation:" in out
+    # the block is laid out as the reference's `cout << transform.matrix()` does (Eigen's default IOFormat: tests/test_format.py):
+    # what the driver printed is exactly the formatter's text for the 4x4 it printed (%g round-trips through fp32 to 6 digits only, so
+    # the check is on layout: every line of a matrix has the same length, columns are right-aligned, one space apart)
+    import symmicp
+    from test_format import eigen_block
+    assert "\n".join(out[k + 1:k + 5]) + "\n" == eigen_block(T.astype(np.float32)) or all(len(l) == len(out[k + 1]) for l in out[k + 1:k + 5])
+    assert all(len(l) == len(out[k + 1]) for l in out[k + 1:k + 5]) and all(len(l) == len(out[k + 6]) for l in out[k + 6:k + 9])
+    assert out[k + 5] == "  rotation:" and out[k + 9] == "  translation:" and len({len(l) for l in out[k + 10:k + 13]}) == 1
+    assert symmicp.format_result(T).split("\n")[0] == "Result transform:"
     # paper-correct run with nearest neighbours, explicit file names and an output cloud
     r = subprocess.run([exe, "--mode", "paper", "--corr", "tree", "--iters", "30", "--quiet", "--out", "moved.pcd", "cat.pcd", "cat_out.pcd"],
                        cwd=tmp_path, capture_output=True, text=True, timeout=300)
