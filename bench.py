@@ -38,7 +38,9 @@ for p in (ROOT, os.path.join(ROOT, "icp-symm_amd", "py")):
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 VALU_PEAK_GINST = 1228.8       # wave64 vector instructions per ns-second: 256 CUs x 4 SIMD-32 x 2.4 GHz / 2 cycles per wave64 op
                                # (= the 157.3 TFLOP/s fp32 vector peak / 128 flops per wave64 FMA)
-PMC_FILE = os.path.join(ROOT, "profiles", "r2_pmc.json")
+PMC_FILE = os.path.join(ROOT, "profiles", "r3_pmc.json")
+N_SIMD = 256 * 4                # CUs x SIMDs
+CLOCK_GHZ = 2.4
 
 
 def main():
@@ -164,6 +166,16 @@ def main():
     elif os.environ.get("SYMMICP_FORCE_COMM"):
         # rehearsal of the multi-GPU data path on one GPU: a real 1-rank RCCL communicator (all-reduce per pass)
         eng.comm_init_rank(1, 0, symmicp.comm_get_unique_id())
+    # the step just before the path (MyICP::estimateNormals, myicp.cpp:152-172): k = 10 PCA normals of this rank's source rows on the GPU,
+    # wall time of the whole call (upload + index build + k_normals_knn + read-back); reported, not part of the timed region (C4 says
+    # "with normals": they are an input).  The first call also loads the code objects: the second is reported.
+    normals_ms = None
+    if args.corr == "tree" and not os.environ.get("SYMMICP_BENCH_NO_NORMALS"):
+        b0, b1 = n_s * rank // world, n_s * (rank + 1) // world
+        symmicp.estimate_normals(d["src"][b0:b0 + 4096], 10)
+        tn0 = time.perf_counter()
+        symmicp.estimate_normals(d["src"][b0:b1], 10, device=local_rank)
+        normals_ms = (time.perf_counter() - tn0) * 1e3
     t0 = time.perf_counter()
     eng.set_target(d["tgt"], d["tgt_n"])
     t1 = time.perf_counter()
@@ -210,9 +222,11 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el = float(t.item())
         st_timed = eng.stats()
+        T_timed = eng.transform()               # (of the timed run itself: the device-driven loop when it ran)
         if best is None or el < best[0]:
-            best = (el, st_timed)
-    elapsed, st_timed = best
+            best = (el, st_timed, T_timed)
+    elapsed, st_timed, T_timed = best
+    err_truth_timed = float(np.abs(T_timed - d["truth"]).max())
     # ---- the same K steps once more with HIP events around EVERY kernel: the per-kernel table.  Kept out of the timed
     # region because each event record costs a few microseconds of GPU timeline, comparable to a converged pass's kernels;
     # this run goes through the host loop (separate search / accumulate / reduce kernels per pass).
@@ -242,10 +256,15 @@ def main():
     else:
         pass_ms = (sum(head[:4]) + converged_ms * (n_all - min(4, len(head)))) / n_all
     n_loc = int(eng.local_count())
+    # wall time per iteration of the converged tail: the timed region minus its first four passes, over the iterations behind them (this
+    # is what an iteration COSTS there: pass kernel + reduce + solve + kernel boundaries; converged_ms is the pass kernel(s) alone)
+    tail_iters = (K + 1) - min(4, len(head))
+    converged_iteration_ms = (elapsed * 1e3 - sum(head[:4])) / tail_iters if tail_iters > 0 and np_timed > 4 else None
     passes = dict(first_ms=round(first_ms, 5) if first_ms is not None else None,
                   second_third_ms=[round(x, 5) for x in second_third],
                   converged_ms=round(converged_ms, 5) if converged_ms is not None else None,
-                  timed=np_timed, of=K + 1, events="every pass" if (all_events or no_events) else "every pass of the host loop, every 4th pass of a device-driven run (standing for the three behind it)", loop="host" if (args.host_loop or os.environ.get("SYMMICP_HOST_LOOP") == "1" or args.exchange in ("shm", "torch")) else "device")
+                  converged_iteration_ms=round(converged_iteration_ms, 5) if converged_iteration_ms is not None else None,
+                  loop_passes=int(st_timed["loop_passes"]), timed=np_timed, of=K + 1, events="every pass" if (all_events or no_events) else "every pass of the host loop, every 4th pass of a device-driven run (standing for the three behind it)", loop="host" if (args.host_loop or os.environ.get("SYMMICP_HOST_LOOP") == "1" or args.exchange in ("shm", "torch")) else "device")
 
     # ---- kernel table of the instrumented run ---------------------------------------------------------
     names = symmicp.KERNEL_SLOTS
@@ -259,7 +278,7 @@ def main():
     achieved = alg_bytes / (pass_ms * 1e-3) / 1e9 if pass_ms > 0 else 0.0
 
     # ---- PMC figures (HBM traffic, vector instructions per launch) cannot be read from inside this process: they come from
-    # the committed rocprofv3 --pmc runs of this same command (profiles/r2_pmc.json; method and dates stated there)
+    # the committed rocprofv3 --pmc runs of this same command (profiles/r3_pmc.json; method and dates stated there)
     pmc, wk = {}, "%s:%d:%s:%s" % (args.workload, n_s, args.mode, args.corr)
     try:
         pj = json.load(open(PMC_FILE))
@@ -268,7 +287,7 @@ def main():
     except Exception:
         pj = None
     traffic = pmc.get("whole_pass_hbm_bytes")
-    traffic_source = ("profiles/r2_pmc.json (%s; %s)" % (wk, pj.get("method", "")) if traffic is not None else None) if pj else None
+    traffic_source = ("profiles/r3_pmc.json (%s; %s)" % (wk, pj.get("method", "")) if traffic is not None else None) if pj else None
     roofline = dict(bound="hbm", achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit="GB/s",
                     frac=round(achieved / HBM_PEAK_GBS, 5), traffic=traffic, traffic_source=traffic_source, kernel=unit_name + " (whole pass)",
                     kernel_ms=round(pass_ms, 5), algorithmic_bytes_per_launch=int(alg_bytes), launches=np_timed,
@@ -282,11 +301,18 @@ def main():
         insts = k.get("valu_wave_insts")
         e = dict(regime=regime, kernel=kernel, ms=round(ms, 5), bound="valu", unit="G wave64-inst/s", peak=VALU_PEAK_GINST,
                  model="vector-instruction issue: instructions per launch (SQ_INSTS_VALU, %s) / live duration; the search kernels are latency- and "
-                       "issue-bound tree / cell walks, not HBM streams" % ("profiles/r2_pmc.json" if insts else "no PMC figure for this workload"),
+                       "issue-bound tree / cell walks, not HBM streams" % ("profiles/r3_pmc.json" if insts else "no PMC figure for this workload"),
                  valu_wave_insts_per_launch=insts, hbm_bytes_per_launch=k.get("hbm_bytes"))
         if insts and ms > 0:
             e["achieved"] = round(insts / (ms * 1e-3) / 1e9, 2)
             e["frac"] = round(e["achieved"] / VALU_PEAK_GINST, 4)
+        act = k.get("valu_active_quad_cycles")
+        if act and ms > 0:
+            # measured: share of the SIMDs' cycles with a vector instruction of some wave in flight (SQ_ACTIVE_INST_VALU quad-cycles x 4
+            # over SIMDs x duration x nominal clock).  The mix of these kernels (readlane, compares, selects, DPP, SGPR operands) issues at
+            # ~4 cycles per instruction, not the 2 of the peak above (scratch/ubench/valu_rates*.hip): this is the figure that says how
+            # much issue capacity is left
+            e["valu_busy_frac"] = round(act * 4.0 / (N_SIMD * ms * 1e-3 * CLOCK_GHZ * 1e9), 4)
         return e
 
     if args.corr == "tree" and first_ms:
@@ -298,9 +324,16 @@ def main():
             fused = passes["loop"] == "device"
             b = n_loc * (76 if fused else 108)      # fused: p 12 + n 12 + record copy 32 + certificate 16 + d2 4; split: cells 52 + accumulate 56
             a = b / (converged_ms * 1e-3) / 1e9
-            regimes.append(dict(regime="converged passes (pairs certified: the pass is a stream)", kernel="k_pass_fused" if fused else "k_search_cells+k_accumulate",
-                                ms=round(converged_ms, 5), bound="hbm", unit="GB/s", peak=HBM_PEAK_GBS, achieved=round(a, 1), frac=round(a / HBM_PEAK_GBS, 4),
-                                bytes_per_launch=int(b), model="bytes the kernels of the pass read and write per point x points / live pass duration"))
+            e = dict(regime="converged passes (pairs certified: the pass is a stream)", kernel="k_pass_fused<true>" if fused else "k_search_cells+k_accumulate",
+                     ms=round(converged_ms, 5), bound="hbm", unit="GB/s", peak=HBM_PEAK_GBS, achieved=round(a, 1), frac=round(a / HBM_PEAK_GBS, 4),
+                     bytes_per_launch=int(b), hbm_bytes_per_launch=pmc.get("kernels", {}).get("converged", {}).get("hbm_bytes"),
+                     model="bytes the kernels of the pass read and write per point x points / live duration of the PASS KERNEL(S) (events around them: the reduce, "
+                           "the solve and the kernel boundaries of an iteration are not inside; frac_of_iteration prices the same bytes against the wall time "
+                           "of a converged iteration)")
+            if converged_iteration_ms:
+                e["iteration_ms"] = round(converged_iteration_ms, 5)
+                e["frac_of_iteration"] = round(b / (converged_iteration_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+            regimes.append(e)
     elif args.corr == "identity":
         regimes.append(dict(regime="identity pairing (what the reference does): one streaming kernel", kernel="k_pass_identity", ms=round(pass_ms, 5), bound="hbm",
                             unit="GB/s", peak=HBM_PEAK_GBS, achieved=round(achieved, 1), frac=round(achieved / HBM_PEAK_GBS, 4), bytes_per_launch=int(alg_bytes),
@@ -347,7 +380,10 @@ def main():
 
     # ---- per-rank figures for N > 1 (a bad scaling curve has to be diagnosable from the line) -------------
     per_rank = None
-    mine = dict(rank=rank, n_loc=n_loc, first_pass_ms=passes["first_ms"], converged_ms=passes["converged_ms"], pass_ms=round(pass_ms, 5),
+    ar_n = int(st_timed.get("allreduce_timed", 0))
+    mine = dict(rank=rank, n_loc=n_loc, first_pass_ms=passes["first_ms"], second_third_ms=passes["second_third_ms"], converged_ms=passes["converged_ms"], pass_ms=round(pass_ms, 5),
+                converged_iteration_ms=passes["converged_iteration_ms"], loop=passes["loop"], loop_passes=passes["loop_passes"],
+                allreduce_us=round(1e3 * st_timed["allreduce_ms"] / ar_n, 2) if ar_n else None, allreduce_timed=ar_n,
                 set_target_ms=round(set_target_s * 1e3, 2), set_source_ms=round(set_source_s * 1e3, 2), kernels_host_loop=kern)
     if dist is not None:
         per_rank = [None] * world
@@ -376,8 +412,9 @@ def main():
             "mcorr_per_sec_first_pass": round(n_loc * world / (first_ms * 1e-3) / 1e6, 2) if first_ms else None,
             "passes": passes,
             "ms_per_step_with_kernel_events": round(elapsed_instrumented / K * 1e3, 5),
-            "final_transform_max_abs_err_vs_truth": err_truth,
-            "setup_ms": {"upload": round(st0["upload_ms"], 2), "index_build": round(st0["build_ms"], 2),
+            "final_transform_max_abs_err_vs_truth": err_truth_timed,
+            "final_transform_max_abs_err_vs_truth_host_loop_run": err_truth,
+            "setup_ms": {"normals": round(normals_ms, 2) if normals_ms is not None else None, "upload": round(st0["upload_ms"], 2), "index_build": round(st0["build_ms"], 2),
                          "set_target": round(set_target_s * 1e3, 2), "set_source": round(set_source_s * 1e3, 2),
                          "set_target+set_source_wall": round(setup_s * 1e3, 2), "grid_level": st0["grid_level"],
                          "tree_levels": st0["tree_levels"]},
@@ -392,6 +429,12 @@ def main():
             if exchange_fallback:
                 out["exchange_fallback_reason"] = fallback_reason
             out["per_rank"] = per_rank
+            # what ONE GPU said about this split beforehand (scratch/predict_ranks.py: N sharded contexts run one after the other, kernel time per
+            # pass, max over ranks): lets a flat curve be attributed to the first pass, the collective or the solve
+            try:
+                out["predicted_per_rank_ms"] = open(os.path.join(ROOT, "profiles", "r3_predict_ranks_%d.log" % world)).read().strip().splitlines()[-1]
+            except OSError:
+                out["predicted_per_rank_ms"] = None
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

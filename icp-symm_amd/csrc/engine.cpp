@@ -233,10 +233,11 @@ struct symmicp_ctx {
     // stats
     int timing = 0;                  // 0 off, 1 two events per pass, 2 events around every kernel of a pass
     // timing mode: 6 events per pass in a ring of kEvRing passes, resolved lazily (no sync inside the loop)
-    static constexpr int kEvRing = 64, kEvPer = 6;
+    static constexpr int kEvRing = 64, kEvPer = 8;      // per pass: 0..4 the kernels, 5 the reduce, 6..7 around the collective (sharded runs)
     hipEvent_t ev[kEvRing * kEvPer] = {};
     int ev_split[kEvRing] = {};      // 1 = split TREE pass (5 kernels), 0 = single pass kernel
     int ev_weight[kEvRing] = {};     // passes this entry stands for (timing mode 3 samples the passes of a device-driven run)
+    int ev_coll[kEvRing] = {};       // 1: events 6 and 7 bracket this pass's all-reduce
     int ev_used = 0;
     symmicp_stats st{};
     // host-side timing of the pass loop, printed by symmicp_destroy under SYMMICP_DEBUG_HOST
@@ -925,6 +926,8 @@ static void flush_events(symmicp_ctx *c)
             if (hipEventElapsedTime(&ms, e[0], e[4]) == hipSuccess) { c->st.kernel_ms[5] += ms; c->st.kernel_launches[5]++; pass_ms += ms; }
             if (hipEventElapsedTime(&ms, e[4], e[5]) == hipSuccess) { c->st.kernel_ms[4] += ms; c->st.kernel_launches[4]++; }
         }
+        if (c->ev_coll[p] && hipEventElapsedTime(&ms, e[6], e[7]) == hipSuccess) { c->st.allreduce_ms += ms; c->st.allreduce_timed++; }
+        c->ev_coll[p] = 0;
         const int w = c->ev_weight[p] > 0 ? c->ev_weight[p] : 1;
         c->st.last_pass_ms = pass_ms;
         c->st.sum_pass_ms += pass_ms * w;
@@ -1107,8 +1110,10 @@ static int run_pass(symmicp_ctx *c, const float Xapply[16], bool from_cur, bool 
         launch_final_reduce(c->partials, blocks, c->d_sums, c->comm ? nullptr : c->h_sums_dev, c->ticket, seq,
                             c->cfg.corr == SYMMICP_CORR_TREE ? c->wl_count : nullptr, keep_nonempty, c->stream);
         if (c->comm) {
+            if (ev) { hipEventRecord(ev[6], c->stream); c->ev_coll[c->ev_used] = 1; }
             int r = g_rccl.AllReduce(c->d_sums, c->d_sums, kNSum, kNcclFloat64, kNcclSum, c->comm, c->stream);
             if (r != 0) return fail(c, SYMMICP_ERR_COMM, std::string("ncclAllReduce: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?"));
+            if (ev) hipEventRecord(ev[7], c->stream);
             launch_publish(c->d_sums, c->h_sums_dev, seq, c->stream);
         }
         // the final-reduce time is only separated out in per-kernel mode; otherwise event 5 is event 4 again
@@ -1192,7 +1197,8 @@ static bool batch_eligible(const symmicp_ctx *c)
     if (c->external_exchange || c->shm.slots) return false;               // those exchanges run on the host
     if (c->timing == 2 || c->ix.dbg) return false;                        // per-kernel tables and debug counters: host loop
     if (c->cfg.mode == SYMMICP_MODE_P2P) return false;                    // (3x3 SVD by Jacobi sweeps: host)
-    if (c->n_loc == 0) return false;
+    if (c->n_loc == 0 && !c->comm) return false;                          // (an empty share of an RCCL run takes part: every input below is global,
+                                                                          // and a rank that stayed in the host loop would issue a different number of all-reduces)
     if (c->host_passes_since_bailout < 2) return false;
     const bool incr = resolved_apply(c->cfg) == SYMMICP_APPLY_INCREMENTAL;
     if (c->cfg.corr == SYMMICP_CORR_IDENTITY) return true;
@@ -1250,6 +1256,7 @@ static int run_batch(symmicp_ctx *c, int want, float *diffs_before, int *n_done,
         const int fb = c->sw.fused_blocks;
         const int tiles = (int)((c->n_loc + kPassThreads - 1) / kPassThreads);
         blocks = tiles < fb ? tiles : fb;
+        if (blocks < 1) blocks = 1;             // (an empty share still writes its zero record)
     } else {
         vec4 = (c->n_loc % 4 == 0) && (c->n_t % 4 == 0) && (c->src_off % 4 == 0);
         const int id_cap = c->sw.id_blocks;
@@ -1301,8 +1308,17 @@ static int run_batch(symmicp_ctx *c, int want, float *diffs_before, int *n_done,
                 // the 40-block reduce is faster than one block's
                 launch_final_reduce(c->partials, blocks, c->d_sums, nullptr, c->ticket, 0ull, counters, 0, c->stream);
                 if (c->comm) {
+                    if (ev) { hipEventRecord(ev[6], c->stream); c->ev_coll[c->ev_used - 1] = 1; }
                     int r = g_rccl.AllReduce(c->d_sums, c->d_sums, kNSum, kNcclFloat64, kNcclSum, c->comm, c->stream);
-                    if (r != 0) return fail(c, SYMMICP_ERR_COMM, std::string("ncclAllReduce: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?"));
+                    if (r != 0) {
+                        // passes are already queued behind this point and (incremental mode) write into `cur`: drain the stream and make the
+                        // context ask for a fresh symmicp_begin -- its loop state no longer describes device memory
+                        (void)hipStreamSynchronize(c->stream);
+                        c->begun = false;
+                        c->ev_used = 0;
+                        return fail(c, SYMMICP_ERR_COMM, std::string("ncclAllReduce: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?"));
+                    }
+                    if (ev) hipEventRecord(ev[7], c->stream);
                 }
                 launch_reduce_solve(c->partials, blocks, c->d_sums, 1, c->d_loop, lc, c->h_ring_dev, symmicp_ctx::kRing, counters, c->stream);
             } else {
@@ -1884,6 +1900,7 @@ int symmicp_reset_stats(symmicp_ctx *c)
     c->st.passes = 0;
     c->st.passes_timed = 0;
     c->st.loop_passes = c->st.loop_straggler_passes = 0;
+    c->st.allreduce_ms = 0.0; c->st.allreduce_timed = 0;
     for (int k = 0; k < 8; k++) { c->st.kernel_ms[k] = 0.0; c->st.kernel_launches[k] = 0; c->st.pass_ms_head[k] = 0.0; }
     return SYMMICP_OK;
 }

@@ -270,6 +270,88 @@ __device__ __noinline__ void pkt_dfs(const float4 *__restrict__ onodes, const fl
     }
 }
 
+// One step of the breadth-first sweep: 8 frontier nodes (fr_cur[f0 .. f0 + 8)) x 8 child slots, one lane per child.  The child's box is tested
+// against the four sub-group boxes and loosest bounds; surviving internal nodes are appended to fr_next (the counter is an LDS word the
+// waves of a packet share); surviving leaves are scanned one after the other against every lane's own bound.  Returns whether a leaf
+// was scanned (the lane's b / thr may have improved).  ND leaves named in `dive` have been scanned already and are skipped.
+template <int ND, bool DBG>
+__device__ __forceinline__ bool pkt_step(const uint32_t *fr_cur, uint32_t *fr_next, uint32_t nf, uint32_t f0, uint32_t off_next, uint32_t *cnt_next, uint32_t front_cap, int lane,
+                                         const float4 *__restrict__ onodes, const float4 *__restrict__ tq, float px, float py, float pz, bool wants,
+                                         const float (&gl)[4][3], const float (&gh)[4][3], const uint32_t (&dive)[ND], PktBest &b, float &thr, PktCounters &cn)
+{
+    constexpr bool CERT = false;
+    const float pad = 0.0f;
+    uint32_t tg[4];
+    {
+        const uint32_t tb = wants ? __float_as_uint(thr) + 1u : 0u;   // 0: the lane wants nothing; else bits + 1 (a bound of 0 still admits gap 0)
+        const uint32_t r = row_umax(tb);
+#pragma unroll
+        for (int g = 0; g < 4; g++) tg[g] = (uint32_t)__builtin_amdgcn_readlane((int)r, 16 * g + 15);
+    }
+    const uint32_t f = f0 + (uint32_t)(lane >> 3), c = (uint32_t)(lane & 7);
+    const uint32_t pkd = (f < nf) ? fr_cur[f] : 0u;
+    const bool valid = c < oct_nch(pkd);
+    float4 cA = make_float4(0.f, 0.f, 0.f, 0.f), cB = cA;
+    bool keep = false;
+    if (valid) {
+        const float4 *__restrict__ ch = onodes + 2 * ((size_t)off_next + oct_cf(pkd) + c);
+        cA = ch[0]; cB = ch[1];
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            // gap between the child's box and the sub-group's box: a lower bound of boxdist2 for each of its lanes
+            const float gx = fmaxf(fmaxf(cA.x - gh[g][0], gl[g][0] - cB.x), 0.0f);
+            const float gy = fmaxf(fmaxf(cA.y - gh[g][1], gl[g][1] - cB.y), 0.0f);
+            const float gz = fmaxf(fmaxf(cA.z - gh[g][2], gl[g][2] - cB.z), 0.0f);
+            keep |= __float_as_uint((gx * gx + gy * gy) + gz * gz) < tg[g];
+        }
+    }
+    const uint32_t cpk = (uint32_t)__float_as_int(cB.w);
+    const bool isleaf = oct_nch(cpk) == 0u;
+    const bool keepL = keep && isleaf, keepI = keep && !isleaf;
+    if (DBG) cn.nodes += (unsigned long long)__popcll(__ballot(valid));
+    // internal survivors -> next frontier
+    const unsigned long long mI = __ballot(keepI);
+    if (mI) {
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(cnt_next, (uint32_t)__popcll(mI));
+        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+        const uint32_t dst = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(mI >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mI, 0u));
+        if (keepI && dst < front_cap) fr_next[dst] = cpk;
+    }
+    // leaf survivors: their lanes fetch the points (all leaves of the step at once), then one leaf at a time
+    unsigned long long mL = __ballot(keepL);
+    bool scanned = false;
+    if (mL) {
+        Pt3 pt[8];
+        if (keepL) {
+            const float4 *__restrict__ lp = tq + (uint32_t)__float_as_int(cA.w);
+#pragma unroll
+            for (int k = 0; k < 8; k++) pt[k] = *reinterpret_cast<const Pt3 *>(lp + k);      // 12-byte loads (tq is padded by 8 entries)
+        }
+        while (mL) {
+            const int src = (int)__ffsll((long long)mL) - 1;
+            mL &= mL - 1ull;
+            if (DBG) cn.leaves++;
+            const uint32_t lfirst = (uint32_t)__builtin_amdgcn_readlane(__float_as_int(cA.w), src);
+            bool dived = false;
+#pragma unroll
+            for (int w = 0; w < ND; w++) dived |= (lfirst == dive[w]);
+            if (dived) continue;                                                 // scanned by a dive already
+            float4 lo, hi;
+            lo.x = bcast(cA.x, src); lo.y = bcast(cA.y, src); lo.z = bcast(cA.z, src);
+            hi.x = bcast(cB.x, src); hi.y = bcast(cB.y, src); hi.z = bcast(cB.z, src);
+            if (__ballot(boxdist2(px, py, pz, lo, hi) <= thr) == 0ull) { if (DBG) cn.rejected++; continue; }
+            const uint32_t cnt = oct_cf((uint32_t)__builtin_amdgcn_readlane((int)cpk, src));
+            if (DBG) cn.points += cnt;
+            pkt_leaf_regs<CERT>(tq, pt, src, lfirst, min(cnt, 8u), px, py, pz, b, cn.ties);
+            if (cnt > 8u) pkt_leaf_scalar<CERT>(tq, lfirst + 8u, cnt - 8u, px, py, pz, b, cn.ties);
+            thr = fminf(thr, pkt_threshold(b.d2, pad));
+            scanned = true;
+        }
+    }
+    return scanned;
+}
+
 // The packets are runs of up to 64 consecutive queries of the Morton-sorted share (PassArgs::pkt_tab, or 64 as they lie): the first pass
 // of an alignment (no previous pairs, every query is searched from scratch).  Later passes have bounds from their previous pairs and
 // mostly certificates; packets were measured there too (previous pair as the bound, certificate test per lane) and lose to the cell
@@ -296,11 +378,15 @@ __device__ __forceinline__ void pkt_sync()
     else __syncthreads();
 }
 
-#ifndef PKT_WAVES
-#define PKT_WAVES 4
+// waves per SIMD the kernels are compiled for (87 / 79 VGPRs; one wave per packet would also fit 6: 0.478 ms against 0.470 at 5 and 0.494 at 4)
+#ifndef PKT_WAVES1
+#define PKT_WAVES1 5
+#endif
+#ifndef PKT_WAVESN
+#define PKT_WAVESN 5
 #endif
 template <int W, bool DBG>
-__global__ __launch_bounds__(64 * W, PKT_WAVES) void k_search_packet(PassArgs a, TargetIndex ix, uint32_t chunk)
+__global__ __launch_bounds__(64 * W, W == 1 ? PKT_WAVES1 : PKT_WAVESN) void k_search_packet(PassArgs a, TargetIndex ix, uint32_t chunk)
 {
     __shared__ float4 s_buf[kPktStack][2];         // BFS: two frontier buffers; DFS fallback: the stack
     __shared__ float s_sb[4][8];                   // bounding boxes of the four 16-query sub-groups
@@ -415,7 +501,6 @@ __global__ __launch_bounds__(64 * W, PKT_WAVES) void k_search_packet(PassArgs a,
             for (int w = 0; w < W; w++) dive_w[w] = s_dive[w];
             int cur = 0;
             bool overflow = false;
-            uint32_t tg[4];
             for (uint32_t level = 0; !done; level++) {
                 const uint32_t nf = s_cnt[level];                       // (written before the barrier: the same in every wave)
                 if (nf == 0u) break;
@@ -432,74 +517,8 @@ __global__ __launch_bounds__(64 * W, PKT_WAVES) void k_search_packet(PassArgs a,
                     if (f0 >= nf) break;
                     if (DBG) { cn.steps++; steps_pk++; }
                     if (W > 1 && wants) thr = __uint_as_float(min(__float_as_uint(thr), s_thr[lane]));      // what the other waves have reached
-                    {
-                        const uint32_t tb = wants ? __float_as_uint(thr) + 1u : 0u;   // 0: the lane wants nothing; else bits + 1 (a bound of 0 still admits gap 0)
-                        const uint32_t r = row_umax(tb);
-#pragma unroll
-                        for (int g = 0; g < 4; g++) tg[g] = (uint32_t)__builtin_amdgcn_readlane((int)r, 16 * g + 15);
-                    }
-                    const uint32_t f = f0 + (uint32_t)(lane >> 3), c = (uint32_t)(lane & 7);
-                    const uint32_t pkd = (f < nf) ? fr[cur][f] : 0u;
-                    const bool valid = c < oct_nch(pkd);
-                    float4 cA = make_float4(0.f, 0.f, 0.f, 0.f), cB = cA;
-                    bool keep = false;
-                    if (valid) {
-                        const float4 *__restrict__ ch = onodes + 2 * ((size_t)off_next + oct_cf(pkd) + c);
-                        cA = ch[0]; cB = ch[1];
-#pragma unroll
-                        for (int g = 0; g < 4; g++) {
-                            // gap between the child's box and the sub-group's box: a lower bound of boxdist2 for each of its lanes
-                            const float gx = fmaxf(fmaxf(cA.x - gh[g][0], gl[g][0] - cB.x), 0.0f);
-                            const float gy = fmaxf(fmaxf(cA.y - gh[g][1], gl[g][1] - cB.y), 0.0f);
-                            const float gz = fmaxf(fmaxf(cA.z - gh[g][2], gl[g][2] - cB.z), 0.0f);
-                            keep |= __float_as_uint((gx * gx + gy * gy) + gz * gz) < tg[g];
-                        }
-                    }
-                    const uint32_t cpk = (uint32_t)__float_as_int(cB.w);
-                    const bool isleaf = oct_nch(cpk) == 0u;
-                    const bool keepL = keep && isleaf, keepI = keep && !isleaf;
-                    if (DBG) cn.nodes += (unsigned long long)__popcll(__ballot(valid));
-                    // internal survivors -> next frontier
-                    const unsigned long long mI = __ballot(keepI);
-                    if (mI) {
-                        uint32_t base = 0;
-                        if (lane == 0) base = atomicAdd(&s_cnt[level + 1], (uint32_t)__popcll(mI));
-                        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-                        const uint32_t dst = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(mI >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mI, 0u));
-                        if (keepI && dst < front_cap) fr[cur ^ 1][dst] = cpk;
-                    }
-                    // leaf survivors: their lanes fetch the points (all leaves of the step at once), then one leaf at a time
-                    unsigned long long mL = __ballot(keepL);
-                    if (mL) {
-                        Pt3 pt[8];
-                        if (keepL) {
-                            const float4 *__restrict__ lp = tq + (uint32_t)__float_as_int(cA.w);
-#pragma unroll
-                            for (int k = 0; k < 8; k++) pt[k] = *reinterpret_cast<const Pt3 *>(lp + k);      // 12-byte loads (tq is padded by 8 entries)
-                        }
-                        bool scanned = false;
-                        while (mL) {
-                            const int src = (int)__ffsll((long long)mL) - 1;
-                            mL &= mL - 1ull;
-                            if (DBG) cn.leaves++;
-                            const uint32_t lfirst = (uint32_t)__builtin_amdgcn_readlane(__float_as_int(cA.w), src);
-                            bool dived = false;
-#pragma unroll
-                            for (int w = 0; w < W; w++) dived |= (lfirst == dive_w[w]);
-                            if (dived) continue;                                                 // scanned by a dive already
-                            float4 lo, hi;
-                            lo.x = bcast(cA.x, src); lo.y = bcast(cA.y, src); lo.z = bcast(cA.z, src);
-                            hi.x = bcast(cB.x, src); hi.y = bcast(cB.y, src); hi.z = bcast(cB.z, src);
-                            if (__ballot(boxdist2(px, py, pz, lo, hi) <= thr) == 0ull) { if (DBG) cn.rejected++; continue; }
-                            const uint32_t cnt = oct_cf((uint32_t)__builtin_amdgcn_readlane((int)cpk, src));
-                            if (DBG) cn.points += cnt;
-                            pkt_leaf_regs<CERT>(tq, pt, src, lfirst, min(cnt, 8u), px, py, pz, b, cn.ties);
-                            if (cnt > 8u) pkt_leaf_scalar<CERT>(tq, lfirst + 8u, cnt - 8u, px, py, pz, b, cn.ties);
-                            thr = fminf(thr, pkt_threshold(b.d2, pad));
-                            scanned = true;
-                        }
-                        if (W > 1 && scanned && wants) thr = __uint_as_float(min(__float_as_uint(thr), atomicMin(&s_thr[lane], __float_as_uint(thr))));
-                    }
+                    const bool scanned = pkt_step<W, DBG>(fr[cur], fr[cur ^ 1], nf, f0, off_next, &s_cnt[level + 1], front_cap, lane, onodes, tq, px, py, pz, wants, gl, gh, dive_w, b, thr, cn);
+                    if (W > 1 && scanned && wants) thr = __uint_as_float(min(__float_as_uint(thr), atomicMin(&s_thr[lane], __float_as_uint(thr))));
                 }
                 cur ^= 1;
                 pkt_sync<W>();
@@ -684,7 +703,7 @@ void launch_accumulate(const PassArgs &a, const float4 *tn, int blocks, hipStrea
 // sharded run, a small cloud -- lasts as long as its slowest packets, and those run W times faster on W waves.
 static uint32_t pick_packet_waves(uint32_t npk)
 {
-    constexpr uint32_t kWaveSlots = 256u * 4u * PKT_WAVES;      // CUs x SIMDs x waves per SIMD of this kernel
+    constexpr uint32_t kWaveSlots = 256u * 4u * PKT_WAVESN;     // CUs x SIMDs x waves per SIMD of the shared-packet kernels
     if (npk >= 4u * kWaveSlots) return 1u;
     if (npk >= 2u * kWaveSlots) return 2u;
     return 4u;

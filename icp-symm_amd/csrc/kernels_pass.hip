@@ -410,6 +410,9 @@ __device__ __forceinline__ void cells_tile(const PassArgs &a, const TargetIndex 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const bool active = i < a.n;
     const float inf = __int_as_float(0x7f800000);
+    // the shard a query is appended to follows the QUERY's own tile of 256, whoever scans it: a block of the streaming kernels strides over
+    // many tiles, and a shard's capacity (shard_capacity) only covers the tiles with (tile & 63) == shard
+    const uint32_t push_shard = from_list ? ((i / kPassThreads) & (uint32_t)(kShards - 1)) : shard;
 
     // ---- phase 1 ----
     float px = 0.f, py = 0.f, pz = 0.f;
@@ -544,7 +547,7 @@ __device__ __forceinline__ void cells_tile(const PassArgs &a, const TargetIndex 
                 a.d2_out[i] = b.d2;
                 a.cert[i].w = 0.0f;           // pairs found by the walk carry no certificate
                 a.pairrec[2 * (size_t)i + 1].w = 2.0f;      // ... and k_accumulate has to fetch their record again
-                sl_push(wl.work, shard, i);
+                sl_push(wl.work, push_shard, i);
             }
         }
     }
@@ -742,7 +745,7 @@ __device__ __forceinline__ void cells_tile(const PassArgs &a, const TargetIndex 
             // the probe could not prove its best: the tree walk takes over from this (tighter) bound
             a.cert[i].w = 0.0f;
             a.pairrec[2 * (size_t)i + 1].w = 2.0f;
-            sl_push(wl.work, shard, i);
+            sl_push(wl.work, push_shard, i);
         } else {
             // certificate for the following passes
             const float second = sqrtf(__uint_as_float(s_second[tid])) * 0.999999f;

@@ -61,7 +61,8 @@ class Stats(C.Structure):
                 ("build_ms", C.c_double), ("upload_ms", C.c_double), ("grid_level", C.c_int32),
                 ("tree_levels", C.c_int32), ("pass_blocks", C.c_int64), ("bytes_algorithmic_per_pass", C.c_int64),
                 ("kernel_ms", C.c_double * 8), ("kernel_launches", C.c_int64 * 8), ("pass_ms_head", C.c_double * 8), ("passes_timed", C.c_int64),
-                ("loop_passes", C.c_int64), ("loop_straggler_passes", C.c_int64), ("packet_fallbacks", C.c_int64)]
+                ("loop_passes", C.c_int64), ("loop_straggler_passes", C.c_int64), ("packet_fallbacks", C.c_int64),
+                ("allreduce_ms", C.c_double), ("allreduce_timed", C.c_int64)]
 
 
 KERNEL_SLOTS = ["k_search_cells", "(gap)", "k_search_walk", "k_accumulate", "k_final_reduce", "single_pass_kernel", "whole_pass"]

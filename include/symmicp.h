@@ -236,6 +236,10 @@ typedef struct {
     /* first passes run as 64-query packets (kernels_packet.hip): packets whose breadth-first frontier outgrew its LDS slot and that
      * finished depth-first instead (exact either way; 0 on the BASELINE workloads), since symmicp_create */
     int64_t packet_fallbacks;
+    /* sharded runs with the library's own RCCL communicator, timing on: HIP-event time spent in the per-pass all-reduce of the record
+     * (events on the ctx stream around the collective) and the number of all-reduces that carried events */
+    double allreduce_ms;
+    int64_t allreduce_timed;
 } symmicp_stats;
 int symmicp_get_stats(symmicp_ctx *ctx, symmicp_stats *out);
 int symmicp_reset_stats(symmicp_ctx *ctx);

@@ -420,6 +420,92 @@ def test_c4_1m_properties(sym, oracle):
     assert r["diff_final"] < 0.2 * r["diff_initial"]
 
 
+def test_c4_1m_final_transform_within_1e4_of_the_oracle(sym, oracle):
+    """north_star's acceptance at its own size: C4 (1M / 1M surface pair with normals), 30 fixed iterations, paper mode -- the GPU's final
+    4x4 against the CPU oracle's run of the same alignment (exact grid NN, all host cores the box gives us), max |dT| <= 1e-4, same
+    iteration count; and the pairs of the 30th pass bit-exact on a 20k sample (myicp.cpp:117-142)."""
+    import os
+    from symmicp import synth
+    d = synth.c4_surface(1_000_000)
+    with sym.Engine(mode=sym.MODE_PAPER, corr=sym.CORR_TREE, max_iters=30, fixed_iters=1) as e:
+        e.set_target(d["tgt"], d["tgt_n"])
+        e.set_source(d["src"], d["src_n"])
+        r = e.align()
+        idx, d2 = e.correspondences()
+        st = e.stats()
+    assert r["status"] == 0 and r["iters"] == 30 and st["loop_passes"] > 0          # (the timed path: device-driven runs of iterations)
+    oracle.set_threads(min(16, os.cpu_count() or 1))
+    try:
+        ro = oracle.align(d["src"], d["src_n"], d["tgt"], d["tgt_n"], mode=oracle.MODE_PAPER, corr=oracle.CORR_GRID, max_iters=30, fixed_iters=True)
+    finally:
+        oracle.set_threads(1)
+    assert ro["status"] == 0 and ro["iters"] == 30
+    assert np.abs(r["transform"] - ro["transform"]).max() <= 1e-4, np.abs(r["transform"] - ro["transform"]).max()
+    assert np.allclose(r["diffs"][:30], ro["diffs"][:30], rtol=2e-4)
+    sub = np.random.default_rng(30).choice(1_000_000, 20000, replace=False)
+    ri, rd = oracle.nn_grid(d["src"][sub], d["tgt"], X=r["transform"])
+    assert np.array_equal(idx[sub], ri) and np.array_equal(d2[sub], rd)
+
+
+def test_align_c3_uniform_100k_brute_force(sym, oracle):
+    """C3 "both BRUTE and GRID": the 100k uniform pair aligned with brute-force correspondences on the GPU against the oracle's exact
+    grid search (both exact nearest neighbours, ties to the lowest row: the same pairs), 30 fixed iterations."""
+    from symmicp import synth
+    d = synth.c3_uniform(100_000)
+    with sym.Engine(mode=sym.MODE_PAPER, corr=sym.CORR_BRUTE, max_iters=30, fixed_iters=1) as e:
+        e.set_target(d["tgt"], d["tgt_n"])
+        e.set_source(d["src"], d["src_n"])
+        r = e.align()
+        idx, d2 = e.correspondences()
+    ro = oracle.align(d["src"], d["src_n"], d["tgt"], d["tgt_n"], mode=oracle.MODE_PAPER, corr=oracle.CORR_GRID, max_iters=30, fixed_iters=True)
+    assert r["status"] == 0 and r["iters"] == ro["iters"] == 30
+    assert np.abs(r["transform"] - ro["transform"]).max() < TOL_T
+    assert np.abs(r["transform"] - d["truth"]).max() < 1e-3
+    ri, rd = oracle.nn_grid(d["src"], d["tgt"], X=r["transform"])
+    assert np.array_equal(idx, ri) and np.array_equal(d2, rd)
+
+
+@pytest.mark.parametrize("workload,n", [("c4", 40000), ("c5", 30000)])
+def test_normals_match_oracle_at_scale(sym, oracle, workload, n):
+    """f1 beyond the 3400-point cat: k = 10 PCA normals of a surface sample and of a scan-like sample (dense rings, noisy ground) against
+    the oracle's k-NN PCA: orientation (viewpoint rule) exact, direction within 0.1 degree on all but the near-isotropic neighbourhoods
+    (myicp.cpp:152-172)."""
+    from symmicp import synth
+    d = dict(c4=synth.c4_surface, c5=synth.c5_scan)[workload](n)
+    vp = (0.5, 0.5, 2.0)
+    for xyz in (d["src"], d["tgt"]):
+        nrm, curv = sym.estimate_normals(xyz, 10, viewpoint=vp)
+        ref, rcurv = oracle.normals_knn(xyz, 10, viewpoint=vp)
+        assert np.abs(np.linalg.norm(nrm, axis=1) - 1).max() < 1e-5
+        dots = np.einsum("ij,ij->i", nrm, ref)
+        # a flipped normal would show as dot = -1: none, apart from neighbourhoods whose smallest eigenvector is ill-defined
+        assert (dots > 0).mean() > 0.9995, (dots > 0).mean()
+        assert (dots > np.cos(np.radians(0.1))).mean() > 0.995, (dots > np.cos(np.radians(0.1))).mean()
+        to_vp = np.asarray(vp, np.float32) - xyz
+        assert (np.einsum("ij,ij->i", nrm, to_vp) >= -1e-6).all()                   # flipped toward the viewpoint, every one
+        assert np.median(np.abs(curv - rcurv)) < 1e-5
+
+
+@pytest.mark.parametrize("waves", ["1", "2", "4"])
+def test_packet_depth_first_fallback_is_entered_and_exact(sym, oracle, monkeypatch, waves):
+    """k_search_packet finishes a packet depth-first (pkt_dfs) when a breadth-first frontier outgrows its LDS slot.  On the BASELINE
+    workloads that no longer happens, so the capacity is shrunk (SYMMICP_PACKET_FRONT_CAP, read at symmicp_create) until it does: the
+    statistics must say the fallback ran, and pairs and distances must stay bit-exact -- with 1, 2 and 4 waves per packet."""
+    from symmicp import synth
+    monkeypatch.setenv("SYMMICP_PACKET_FRONT_CAP", "8")
+    monkeypatch.setenv("SYMMICP_FIRST_PASS", "packet")
+    monkeypatch.setenv("SYMMICP_PACKET_WAVES", waves)
+    for d in (synth.c4_surface(30000), synth.c3_uniform(6000)):
+        with sym.Engine(mode=sym.MODE_PAPER, corr=sym.CORR_TREE) as e:
+            e.set_target(d["tgt"], d["tgt_n"])
+            e.set_source(d["src"], d["src_n"])
+            e.begin()
+            idx, d2 = e.correspondences()
+            assert e.stats()["packet_fallbacks"] > 0
+        ri, rd = oracle.nn_grid(d["src"], d["tgt"])
+        assert np.array_equal(idx, ri) and np.array_equal(d2, rd)
+
+
 def test_8m_surface_properties(sym, oracle):
     """BASELINE's largest size (C5: 8M/8M) on the fast C4-style generator (the ray-cast C5 generator needs minutes of
     host time): the size-dependent machinery -- 8M-key radix sorts, 31k-block grids, level-10 cell table -- must still
@@ -846,14 +932,16 @@ def test_forced_repair_path_in_a_subprocess(sym):
     assert " passed" in r.stdout
 
 
-@pytest.mark.parametrize("regime", ["packet", "walk"])
+@pytest.mark.parametrize("regime", ["packet", "packet:1", "packet:4", "walk"])
 def test_first_pass_regimes_forced_in_a_subprocess(sym, regime):
     """The first pass of an alignment runs as 64-query packets (kernels_packet.hip) on surface-like targets and as the
     per-thread octree walk on volume-like ones (engine.cpp, build_index).  SYMMICP_FIRST_PASS forces one regime on every
     target -- volume clouds, tiny and ragged sizes, duplicates and ties, far queries included: pairs and distances must
     stay bit-exact against the oracle either way."""
     import subprocess
-    env = dict(os.environ, SYMMICP_FIRST_PASS=regime)
+    env = dict(os.environ, SYMMICP_FIRST_PASS=regime.split(":")[0])
+    if ":" in regime:
+        env["SYMMICP_PACKET_WAVES"] = regime.split(":")[1]          # waves that share a packet (default: chosen from the packet count)
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
                         "-k", "nn_exact or nn_scanlike or tree_follows_previous_pairs or randomised_exactness or partial_overlap or sharded_ranks or align_paper_recovers"],
                        env=env, capture_output=True, text=True, timeout=900)
