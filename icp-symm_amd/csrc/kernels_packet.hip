@@ -16,10 +16,10 @@
 //             CHILD: the lane loads the child's 32-byte record (all loads of a step are independent) and tests its box
 //             against the bounding boxes and loosest bounds of the packet's four 16-query sub-groups (wave-uniform SGPR
 //             operands).  Surviving internal nodes are compacted into the next frontier (ballot + mbcnt)
-//   leaves    a surviving leaf's lane also loads the leaf's points (up to 8, 16 bytes each) into its own registers: all
-//             leaves of a step load at once.  Leaves are then taken one at a time: box and points are broadcast with
-//             v_readlane (SGPR operands), every lane tests the box against its own bound (no lane needs it -> skip), then
-//             the points: ~14 vector instructions per point for all 64 queries; bounds tighten as leaves are scanned
+//   leaves    surviving leaves are taken one at a time: the box is broadcast with v_readlane (SGPR operands), every lane tests it
+//             against its own bound (no lane needs it -> skip), then the leaf's points arrive through the SCALAR cache (s_load,
+//             8 points per round trip) and are tested as SGPR operands: ~12 vector instructions per point for all 64 queries;
+//             bounds tighten as leaves are scanned
 // A packet is ~25 dependent round trips and ~12 k vector instructions instead of ~300 and ~21 k.
 //
 // Exactness.  A box is skipped only when boxdist2 (the same monotone fp32 expression as dist2, so boxdist2 <= dist2 to
@@ -164,36 +164,6 @@ __device__ __forceinline__ float bcast(float v, int src_lane)
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src_lane));
 }
 
-// the first m (<= 8) points of the leaf sit in the registers pt[0..7] of lane `src` (wave-uniform): broadcast and test.  Only the coordinates
-// are kept in registers (24 instead of 32: the kernel's occupancy is register-bound); the rows a tie needs are read from memory (rare)
-struct Pt3 { float x, y, z; };
-template <bool CERT>
-__device__ __forceinline__ void pkt_leaf_regs(const float4 *__restrict__ tq, const Pt3 (&pt)[8], int src, uint32_t first, uint32_t m, float px,
-                                              float py, float pz, PktBest &b, unsigned long long &c_tie)
-{
-    int32_t slot = 8;
-    unsigned long long tie = 0;
-    pkt_point<CERT, 0>(b, slot, tie, px, py, pz, bcast(pt[0].x, src), bcast(pt[0].y, src), bcast(pt[0].z, src));
-    if (m > 1u) pkt_point<CERT, 1>(b, slot, tie, px, py, pz, bcast(pt[1].x, src), bcast(pt[1].y, src), bcast(pt[1].z, src));
-    if (m > 2u) pkt_point<CERT, 2>(b, slot, tie, px, py, pz, bcast(pt[2].x, src), bcast(pt[2].y, src), bcast(pt[2].z, src));
-    if (m > 3u) pkt_point<CERT, 3>(b, slot, tie, px, py, pz, bcast(pt[3].x, src), bcast(pt[3].y, src), bcast(pt[3].z, src));
-    if (m > 4u) pkt_point<CERT, 4>(b, slot, tie, px, py, pz, bcast(pt[4].x, src), bcast(pt[4].y, src), bcast(pt[4].z, src));
-    if (m > 5u) pkt_point<CERT, 5>(b, slot, tie, px, py, pz, bcast(pt[5].x, src), bcast(pt[5].y, src), bcast(pt[5].z, src));
-    if (m > 6u) pkt_point<CERT, 6>(b, slot, tie, px, py, pz, bcast(pt[6].x, src), bcast(pt[6].y, src), bcast(pt[6].z, src));
-    if (m > 7u) pkt_point<CERT, 7>(b, slot, tie, px, py, pz, bcast(pt[7].x, src), bcast(pt[7].y, src), bcast(pt[7].z, src));
-    if (slot != 8) b.pos = (int32_t)first + slot;
-    if (tie != 0ull) {
-        c_tie++;
-        int32_t brow = (b.pos >= 0) ? __float_as_int(tq[b.pos].w) : 0x7fffffff;
-        for (uint32_t k = 0; k < m; k++) {
-            const float4 q = tq[first + k];                    // (wave-uniform address)
-            const float d2 = dist2(px, py, pz, q.x, q.y, q.z);
-            const int32_t row = __float_as_int(q.w);
-            if (d2 == b.d2 && row < brow) { brow = row; b.pos = (int32_t)(first + k); }
-        }
-    }
-}
-
 // ---- depth-first traversal shared by the wave (fallback when a frontier outgrows its LDS slot) -------------------------
 // pop a node (its 32-byte record travels on the stack); every lane tests the node's box against its own bound; no lane
 // wants it -> next pop; leaf -> scan; internal -> lane 4c+g tests child c against sub-group g's box and bound, the
@@ -318,16 +288,10 @@ __device__ __forceinline__ bool pkt_step(const uint32_t *fr_cur, uint32_t *fr_ne
         const uint32_t dst = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(mI >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mI, 0u));
         if (keepI && dst < front_cap) fr_next[dst] = cpk;
     }
-    // leaf survivors: their lanes fetch the points (all leaves of the step at once), then one leaf at a time
+    // leaf survivors: one leaf at a time
     unsigned long long mL = __ballot(keepL);
     bool scanned = false;
     if (mL) {
-        Pt3 pt[8];
-        if (keepL) {
-            const float4 *__restrict__ lp = tq + (uint32_t)__float_as_int(cA.w);
-#pragma unroll
-            for (int k = 0; k < 8; k++) pt[k] = *reinterpret_cast<const Pt3 *>(lp + k);      // 12-byte loads (tq is padded by 8 entries)
-        }
         while (mL) {
             const int src = (int)__ffsll((long long)mL) - 1;
             mL &= mL - 1ull;
@@ -343,8 +307,10 @@ __device__ __forceinline__ bool pkt_step(const uint32_t *fr_cur, uint32_t *fr_ne
             if (__ballot(boxdist2(px, py, pz, lo, hi) <= thr) == 0ull) { if (DBG) cn.rejected++; continue; }
             const uint32_t cnt = oct_cf((uint32_t)__builtin_amdgcn_readlane((int)cpk, src));
             if (DBG) cn.points += cnt;
-            pkt_leaf_regs<CERT>(tq, pt, src, lfirst, min(cnt, 8u), px, py, pz, b, cn.ties);
-            if (cnt > 8u) pkt_leaf_scalar<CERT>(tq, lfirst + 8u, cnt - 8u, px, py, pz, b, cn.ties);
+            // the leaf's points come through the scalar cache, 8 at a time (one dependent round trip per 8 points, hidden by the other waves of the
+            // SIMD: the kernel is bound by vector-instruction issue).  Round 2 had the leaf's lane load them into 32 vector registers and
+            // broadcast them with three v_readlane per point -- 4 cycles of vector issue each: 0.483 against 0.471 ms at 1M, 0.58 against 0.53 at 2M
+            pkt_leaf_scalar<CERT>(tq, lfirst, cnt, px, py, pz, b, cn.ties);
             thr = fminf(thr, pkt_threshold(b.d2, pad));
             scanned = true;
         }
