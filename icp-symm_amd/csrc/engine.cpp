@@ -36,6 +36,7 @@ void read_switches(Switches &w)
     { const char *e = std::getenv("SYMMICP_HOST_LOOP"); w.host_loop = e && e[0] == '1'; }
     w.no_loop_stragglers = flag("SYMMICP_NO_LOOP_STRAGGLERS");
     w.force_comm = flag("SYMMICP_FORCE_COMM");
+    if (const char *e = std::getenv("SYMMICP_PACKET_COST_KEY")) w.packet_cost_key = e[0] != '0';
     w.budget_walk = tri("SYMMICP_BUDGET_WALK");
     w.optimistic = tri("SYMMICP_OPTIMISTIC");
     w.compact = tri("SYMMICP_COMPACT");
@@ -643,6 +644,8 @@ int symmicp_set_source(symmicp_ctx *c, const float *xyz, size_t xr, size_t xc, c
             HIP_TRY(c, hipMemcpyAsync(&npk, cnt.p, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
             HIP_TRY(c, hipStreamSynchronize(c->stream));
             if (npk < nblk || npk > cap) { forget_source(c); return fail(c, SYMMICP_ERR_HIP, "packet table: count out of range"); }
+            // the target is known already: key the start order by what a packet will cost (its distance to the target), not by its extent alone
+            if (c->have_index && c->ix.onodes && key_bits > 0 && c->sw.packet_cost_key) launch_packet_cost(c->src0, runs.p, npk, c->ix, keys.p, key_bits, c->stream);
             radix_sort_pairs(keys.p, vals.p, kt.p, vt.p, npk, key_bits > 0 ? key_bits : 32, ws.p, wse, c->stream);
             c->pkt_tab = reinterpret_cast<uint32_t *>(c->src_all + o_pkt);
             c->pkt_count = npk;

@@ -85,6 +85,7 @@ struct Switches {
     int first_pass = -1;                   // -1: decided per target (build_index); 0: per-thread walk; 1: packets
     int oct_leaf = 0;                      // octree leaf size (0: 16 on surface-like targets, 8 otherwise)
     bool packet_order = true;              // packets started longest-first
+    bool packet_cost_key = true;           // ... keyed by their distance to the target when it is known at set_source (0: by radius alone)
     float packet_jump = -1.0f;             // cut factor of k_packet_runs (< 0: the default, 0: never cut)
     int packet_key_bits = 16;
     uint32_t packet_chunk = 0, packet_lds_pad = 0, packet_waves = 0, packet_front_cap = 0;

@@ -643,6 +643,57 @@ __global__ __launch_bounds__(64) void k_packet_runs(CloudSoA src, uint32_t n, fl
     }
 }
 
+// A better start key when the target is already known (set_target before set_source): what a packet costs is set by how far its queries are from
+// the target, which its radius does not see -- the packets that end a launch are the ones 3 to 5 times the median distance away (their balls touch
+// ten times the leaves).  One wave per run: centroid, greedy descent of the target's octree to the leaf nearest to it (as the search's own dive),
+// distance d to that leaf's nearest point; the ball of radius d + r around the centroid cuts a disc of area ~ 2 d r + r^2 out of a surface: that
+// is the key.  Evaluated under the IDENTITY transform (the usual initial guess): another guess only changes the start order, never a result.
+__global__ __launch_bounds__(64) void k_packet_cost(CloudSoA src, const uint2 *__restrict__ runs, uint32_t npk, TargetIndex ix, uint32_t *__restrict__ keys, int key_bits)
+{
+    const uint32_t k = blockIdx.x;
+    if (k >= npk) return;
+    const int lane = threadIdx.x;
+    const uint2 run = runs[k];
+    const bool active = (uint32_t)lane < run.y;
+    const uint32_t i = run.x + (uint32_t)lane;
+    const float x = active ? src.x[i] : 0.f, y = active ? src.y[i] : 0.f, z = active ? src.z[i] : 0.f;
+    float ax = x, ay = y, az = z, ac = active ? 1.f : 0.f;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { ax += __shfl_xor(ax, off, 64); ay += __shfl_xor(ay, off, 64); az += __shfl_xor(az, off, 64); ac += __shfl_xor(ac, off, 64); }
+    const float cx = ax / ac, cy = ay / ac, cz = az / ac;
+    float r2 = active ? dist2(x, y, z, cx, cy, cz) : 0.f;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) r2 = fmaxf(r2, __shfl_xor(r2, off, 64));
+    // greedy descent: at every level the child whose box is nearest to the centroid
+    const float4 rootA = ix.onodes[0], rootB = ix.onodes[1];
+    uint32_t first = (uint32_t)__float_as_int(rootA.w), packed = (uint32_t)__float_as_int(rootB.w), level = 0;
+    while (oct_nch(packed) != 0u) {
+        const uint32_t nch = oct_nch(packed), cf = oct_cf(packed);
+        uint32_t key = 0xFFFFFFFFu;
+        float4 cA = make_float4(0.f, 0.f, 0.f, 0.f), cB = cA;
+        if ((uint32_t)lane < nch) {
+            const float4 *__restrict__ ch = ix.onodes + 2 * ((size_t)ix.olevel_off[level + 1] + cf + (uint32_t)lane);
+            cA = ch[0]; cB = ch[1];
+            key = (__float_as_uint(boxdist2(cx, cy, cz, cA, cB)) & ~7u) | (uint32_t)lane;
+        }
+        key = dpp_umin<0x111, 0xf>(key); key = dpp_umin<0x112, 0xf>(key); key = dpp_umin<0x114, 0xf>(key);
+        const int cmin = __builtin_amdgcn_readlane((int)key, 7) & 7;
+        packed = (uint32_t)__builtin_amdgcn_readlane(__float_as_int(cB.w), cmin);
+        first = (uint32_t)__builtin_amdgcn_readlane(__float_as_int(cA.w), cmin);
+        level++;
+    }
+    const uint32_t cnt = oct_cf(packed);
+    float d2 = __int_as_float(0x7f800000);
+    if ((uint32_t)lane < cnt) { const float4 q = ix.tq[first + (uint32_t)lane]; d2 = dist2(cx, cy, cz, q.x, q.y, q.z); }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) d2 = fminf(d2, __shfl_xor(d2, off, 64));
+    if (lane == 0) {
+        const float cost = 2.0f * sqrtf(d2) * sqrtf(r2) + r2;
+        const float c2 = (cost == cost && cost < 3.0e38f) ? cost : r2;
+        keys[k] = key_bits >= 32 ? ~__float_as_uint(c2) : ((1u << key_bits) - 1u) - (__float_as_uint(c2) >> (32 - key_bits));
+    }
+}
+
 // the packet table in start order
 __global__ __launch_bounds__(256) void k_packet_table(const uint32_t *__restrict__ order, const uint2 *__restrict__ runs, uint32_t npk, uint2 *__restrict__ tab)
 {
@@ -654,6 +705,11 @@ void launch_packet_runs(const CloudSoA &src, uint32_t n, float jump_factor, uint
 {
     const uint32_t nblk = (n + 63u) / 64u;
     if (nblk) hipLaunchKernelGGL(k_packet_runs, dim3(nblk), dim3(64), 0, s, src, n, jump_factor < 0.f ? kJumpFactor : jump_factor, runs, keys, vals, count, key_bits);
+}
+
+void launch_packet_cost(const CloudSoA &src, const uint2 *runs, uint32_t npk, const TargetIndex &ix, uint32_t *keys, int key_bits, hipStream_t s)
+{
+    if (npk) hipLaunchKernelGGL(k_packet_cost, dim3(npk), dim3(64), 0, s, src, runs, npk, ix, keys, key_bits);
 }
 
 void launch_packet_table(const uint32_t *order, const uint2 *runs, uint32_t npk, uint2 *tab, hipStream_t s)

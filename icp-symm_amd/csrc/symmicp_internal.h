@@ -202,6 +202,8 @@ void launch_gather_soa(const CloudSoA &src, const uint32_t *order, uint32_t n, C
 void launch_offset_u32(const uint32_t *in, uint32_t off, uint32_t n, uint32_t *out, hipStream_t s);
 // first pass: the packets (runs of <= 64 queries, blocks cut at jumps of the Morton curve; jump_factor < 0: the default) with radius keys, and the table in start order
 void launch_packet_runs(const CloudSoA &src, uint32_t n, float jump_factor, uint2 *runs, uint32_t *keys, uint32_t *vals, uint32_t *count, int key_bits, hipStream_t s);
+// start keys from the packets' distance to the target (identity transform): replaces the radius keys of launch_packet_runs when the target index exists
+void launch_packet_cost(const CloudSoA &src, const uint2 *runs, uint32_t npk, const TargetIndex &ix, uint32_t *keys, int key_bits, hipStream_t s);
 void launch_packet_table(const uint32_t *order, const uint2 *runs, uint32_t npk, uint2 *tab, hipStream_t s);
 void launch_deinterleave3(const float *raw, size_t row_stride, size_t offset, uint32_t n, float *x, float *y, float *z, hipStream_t s);
 void launch_level_hist(const uint32_t *keys, uint32_t n, uint32_t *hist16, hipStream_t s);
