@@ -81,9 +81,8 @@ __device__ __forceinline__ void acc_pair(Acc &a, float px, float py, float pz, f
     a.v[36] += (double)d2;
 }
 
-// wave64 sum on the VALU's DPP cross-lane network (no LDS traffic): row_shr 1,2,4,8 builds 16-lane row
-// sums, row_bcast15 / row_bcast31 carry them across rows; the total ends up in lane 63.  A double moves as
-// two 32-bit DPP movs; lanes without a source read 0 (bound_ctrl), i.e. add +0.0.
+// one step of a sum on the VALU's DPP cross-lane network (no LDS traffic): row_shr 1,2,4,8 builds 16-lane row sums.  A double moves
+// as two 32-bit DPP movs; lanes without a source read 0 (bound_ctrl), i.e. add +0.0.
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ double dpp_add_f64(double x)
 {
@@ -92,29 +91,47 @@ __device__ __forceinline__ double dpp_add_f64(double x)
     return x + __hiloint2double(hi, lo);
 }
 
-__device__ __forceinline__ double wave_sum_to_lane63(double x)
+// wave64 sums of the 37 accumulators by halving: v_permlane32_swap puts the upper half-wave of value k next to the lower half-wave of
+// value k + 20 (one add sums both values' halves: lanes 0..31 carry k, lanes 32..63 carry k + 20), v_permlane16_swap does the same
+// with 16-lane rows for k and k + 10, and only the last four steps (row_shr 1, 2, 4, 8 inside a row of 16) touch every remaining
+// register: 70 fp64 adds and 140 cross-lane moves per wave instead of the 222 + 444 of a full DPP reduction per value (2.4 us of the
+// fused pass's 25 on its own stamps).  Lane 16 r + 15 then holds the wave's sum of value k + 10 r.
+typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ double swap32_add(double a, double b)
 {
-    x = dpp_add_f64<0x111, 0xf>(x);      // row_shr:1
-    x = dpp_add_f64<0x112, 0xf>(x);      // row_shr:2
-    x = dpp_add_f64<0x114, 0xf>(x);      // row_shr:4
-    x = dpp_add_f64<0x118, 0xf>(x);      // row_shr:8  -> lane 15 of each row holds the row sum
-    x = dpp_add_f64<0x142, 0xa>(x);      // row_bcast15 into rows 1 and 3
-    x = dpp_add_f64<0x143, 0xc>(x);      // row_bcast31 into rows 2 and 3 -> lane 63 holds the wave sum
-    return x;
+    const u32x2_t lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+    const u32x2_t hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+    return __hiloint2double((int)hi.x, (int)lo.x) + __hiloint2double((int)hi.y, (int)lo.y);
+}
+__device__ __forceinline__ double swap16_add(double a, double b)
+{
+    const u32x2_t lo = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+    const u32x2_t hi = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+    return __hiloint2double((int)hi.x, (int)lo.x) + __hiloint2double((int)hi.y, (int)lo.y);
 }
 
-// block reduction: DPP wave sums, then LDS across the 4 waves; fixed order -> deterministic.
+// block reduction: wave sums, then LDS across the 4 waves; fixed order -> deterministic.
 // record k of block b lands at partials[b * kNSum + k]: one contiguous 320-byte burst per block.  (Round 2 stored it transposed,
 // [k][block], so that the reduce could read along the blocks: 40 scattered 8-byte stores per block into lines shared with up to 15
 // other blocks -- on other XCDs, i.e. other L2s -- and a reduce whose load phase alone took 5.9 us of k_reduce_solve's 11.5.)
 __device__ __forceinline__ void acc_block_reduce_store(Acc &a, double *partials, uint32_t nblocks, uint32_t col)
 {
+    static_assert(kNSum == 40 && kNAcc <= 40, "the halving below pairs value k with k + 20, then k + 10");
     __shared__ double red[(kPassThreads / 64) * kNSum];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double h1[20], h2[10];
 #pragma unroll
-    for (int k = 0; k < kNAcc; k++) {
-        const double x = wave_sum_to_lane63(a.v[k]);
-        if (lane == 63) red[wave * kNSum + k] = x;
+    for (int k = 0; k < 20; k++) h1[k] = swap32_add(k < kNAcc ? a.v[k] : 0.0, k + 20 < kNAcc ? a.v[k + 20] : 0.0);
+#pragma unroll
+    for (int k = 0; k < 10; k++) h2[k] = swap16_add(h1[k], h1[k + 10]);
+#pragma unroll
+    for (int k = 0; k < 10; k++) {
+        double x = h2[k];
+        x = dpp_add_f64<0x111, 0xf>(x);      // row_shr:1
+        x = dpp_add_f64<0x112, 0xf>(x);      // row_shr:2
+        x = dpp_add_f64<0x114, 0xf>(x);      // row_shr:4
+        x = dpp_add_f64<0x118, 0xf>(x);      // row_shr:8  -> lane 15 of each row holds the row sum
+        if ((lane & 15) == 15) red[wave * kNSum + k + 10 * (lane >> 4)] = x;
     }
     __syncthreads();
     if (threadIdx.x < kNSum) {
@@ -799,13 +816,38 @@ __global__ __launch_bounds__(kPassThreads) void k_search_cells(PassArgs a, Targe
 // ---------------------------------------------------------------------------
 constexpr int kFusedList = 2048;      // (>= two tiles of the fused pass: a tile is 1024 points there)
 
-__device__ __forceinline__ void fused_accumulate(Acc &acc, const PassArgs &a, const Affine &X, float nx, float ny, float nz, float px, float py, float pz,
+// What the streaming loop of k_pass_fused needs of its arguments, held in VECTOR registers.  The kernel's three argument structs are ~150
+// scalars, all live across the loop (the scan behind it needs them); with 102 scalar registers per wave the compiler parked them in the
+// lanes of a vector register and fetched them back one v_readlane at a time: 85 of the loop's 291 vector instructions per tile.  Values
+// that pass through in_vgpr are opaque to it: they stay where they are (and VGPR operands issue faster than scalar ones).
+template <typename T>
+__device__ __forceinline__ T in_vgpr(T v)
+{
+    asm volatile("" : "+v"(v));
+    return v;
+}
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+template <typename T>
+__device__ __forceinline__ __attribute__((address_space(1))) T *gcol(unsigned long long base)      // a global-memory pointer from its address (an opaque pointer would load as `flat`)
+{
+    return (__attribute__((address_space(1))) T *)base;
+}
+__device__ __forceinline__ float4 as_float4(f32x4_t v) { return make_float4(v.x, v.y, v.z, v.w); }
+struct HotParams {
+    Affine X;
+    float pivot[3];
+    float max_d2, min_ndot;
+    int32_t p2p;
+};
+
+__device__ __forceinline__ void fused_accumulate(Acc &acc, const HotParams &h, float nx, float ny, float nz, float px, float py, float pz,
                                                  const float4 &q, const float4 &nq, float d2)
 {
+    const Affine &X = h.X;
     const float npx = xf_row(X.m + 0, nx, ny, nz, X.nrm_w), npy = xf_row(X.m + 4, nx, ny, nz, X.nrm_w), npz = xf_row(X.m + 8, nx, ny, nz, X.nrm_w);
-    if (a.max_d2 > 0.0f && d2 > a.max_d2) return;
-    if (a.min_ndot > -1.0f && (npx * nq.x + npy * nq.y) + npz * nq.z < a.min_ndot) return;
-    acc_pair(acc, px, py, pz, npx, npy, npz, q.x, q.y, q.z, nq.x, nq.y, nq.z, d2, a.pivot, a.p2p);
+    if (h.max_d2 > 0.0f && d2 > h.max_d2) return;
+    if (h.min_ndot > -1.0f && (npx * nq.x + npy * nq.y) + npz * nq.z < h.min_ndot) return;
+    acc_pair(acc, px, py, pz, npx, npy, npz, q.x, q.y, q.z, nq.x, nq.y, nq.z, d2, h.pivot, h.p2p);
 }
 
 #ifndef FUSED_WAVES
@@ -827,16 +869,48 @@ __global__ __launch_bounds__(kPassThreads, ACC ? FUSED_WAVES : COMPACT_WAVES) vo
     constexpr int kList = ACC ? kFusedList : kFusedList / 2;      // (the search-only form keeps 5 workgroups per CU: its tile is 256 points)
     __shared__ uint32_t s_list[kList];
     __shared__ uint32_t s_cnt, s_total;
+    __shared__ unsigned long long s_col[ACC ? 10 : 1];      // base addresses of the streamed columns (read back at the top of every tile: see in_vgpr)
     // device-driven loop: stop flag and transform come from device memory, written by the kernel just before this one -- a cold round trip.
     // They are requested here and first LOOKED AT behind the first tile's loads (which do not depend on them): one round trip, not two
     // (behind the barrier: scalar loads and LDS stores share a counter, and the barrier waits for it)
     Acc acc;
     if (ACC) acc_zero(acc);
     if (threadIdx.x == 0) { s_cnt = 0; s_total = 0; }
+    if (ACC && threadIdx.x == 0) {
+        s_col[0] = (unsigned long long)a.in.x; s_col[1] = (unsigned long long)a.in.y; s_col[2] = (unsigned long long)a.in.z;
+        s_col[3] = (unsigned long long)a.in.nx; s_col[4] = (unsigned long long)a.in.ny; s_col[5] = (unsigned long long)a.in.nz;
+        s_col[6] = (unsigned long long)a.pairrec; s_col[7] = (unsigned long long)a.cert; s_col[8] = (unsigned long long)a.d2_out;
+    }
     __syncthreads();
     int stop = 0;
-    Affine X = a.X;
-    if (a.loop) { stop = a.loop->stop; X = a.loop->Xapply; }
+    HotParams h;
+    if (ACC && a.loop) {
+        // (vector loads through a pointer the compiler cannot see through: the transform arrives in VGPRs, behind the first tile's loads like the flag)
+        stop = a.loop->stop;
+        const float4 *xp = reinterpret_cast<const float4 *>(&in_vgpr(a.loop)->Xapply);
+        const float4 r0 = xp[0], r1 = xp[1], r2 = xp[2];
+        h.X.m[0] = r0.x; h.X.m[1] = r0.y; h.X.m[2] = r0.z; h.X.m[3] = r0.w;
+        h.X.m[4] = r1.x; h.X.m[5] = r1.y; h.X.m[6] = r1.z; h.X.m[7] = r1.w;
+        h.X.m[8] = r2.x; h.X.m[9] = r2.y; h.X.m[10] = r2.z; h.X.m[11] = r2.w;
+        h.X.nrm_w = reinterpret_cast<const float *>(xp)[12];
+    } else if (ACC) {
+#pragma unroll
+        for (int k = 0; k < 12; k++) h.X.m[k] = in_vgpr(a.X.m[k]);
+        h.X.nrm_w = in_vgpr(a.X.nrm_w);
+    } else {
+        // (the search-only form runs at 5 waves per SIMD, 96 registers: no room for resident copies)
+        h.X = a.X;
+        if (a.loop) { stop = a.loop->stop; h.X = a.loop->Xapply; }
+    }
+    const Affine &X = h.X;
+#pragma unroll
+    for (int k = 0; k < 3; k++) h.pivot[k] = ACC ? in_vgpr(a.pivot[k]) : a.pivot[k];
+    h.max_d2 = ACC ? in_vgpr(a.max_d2) : a.max_d2; h.min_ndot = ACC ? in_vgpr(a.min_ndot) : a.min_ndot;
+    h.p2p = a.p2p;
+#ifdef RS_STAMPS2
+    const unsigned long long fs0 = __builtin_amdgcn_s_memrealtime();
+    unsigned long long fs1 = 0;
+#endif
     const uint32_t shard = blockIdx.x & (kShards - 1);
 
     // the listed queries (their single certificate has failed): (ACC) first the neighbourhood certificate -- the winner is a member of the set
@@ -865,7 +939,7 @@ __global__ __launch_bounds__(kPassThreads, ACC ? FUSED_WAVES : COMPACT_WAVES) vo
                     if (pw != pk) { qw = ix.tn[2 * (size_t)pw]; nqw = ix.tn[2 * (size_t)pw + 1]; }
                     a.d2_out[i] = d2w;
                     const float nx = a.in.nx[i], ny = a.in.ny[i], nz = a.in.nz[i];
-                    fused_accumulate(acc, a, X, nx, ny, nz, px, py, pz, qw, nqw, d2w);
+                    fused_accumulate(acc, h, nx, ny, nz, px, py, pz, qw, nqw, d2w);
                     s_list[e] = 0xFFFFFFFFu;                       // settled (an idle lane of the scan below)
                 }
             }
@@ -887,7 +961,7 @@ __global__ __launch_bounds__(kPassThreads, ACC ? FUSED_WAVES : COMPACT_WAVES) vo
                 const float x = a.in.x[i], y = a.in.y[i], z = a.in.z[i];
                 const float nx = a.in.nx[i], ny = a.in.ny[i], nz = a.in.nz[i];
                 const float px = xf_row(X.m + 0, x, y, z, 1.0f), py = xf_row(X.m + 4, x, y, z, 1.0f), pz = xf_row(X.m + 8, x, y, z, 1.0f);
-                fused_accumulate(acc, a, X, nx, ny, nz, px, py, pz, q, nq, dist2(px, py, pz, q.x, q.y, q.z));
+                fused_accumulate(acc, h, nx, ny, nz, px, py, pz, q, nq, dist2(px, py, pz, q.x, q.y, q.z));
             }
         }
         __syncthreads();
@@ -910,6 +984,7 @@ __global__ __launch_bounds__(kPassThreads, ACC ? FUSED_WAVES : COMPACT_WAVES) vo
     // ---- stream (tile numbers are dealt so that each XCD works on one contiguous part of the sorted source)
     for (uint32_t t = blockIdx.x; t < tiles_p; t += gridDim.x) {
         const uint32_t i0 = (ACC ? xcd_remap(t, tiles_p) : xcd_remap_chunked(t, kTileChunk)) * kTilePts + threadIdx.x;
+        if (ACC) asm volatile("" ::: "memory");        // (the column table is read here, per tile: hoisted out of the loop it would be 24 more live registers)
         // one round trip: everything the common case (certified pair) needs.  (Measured and dropped: letting the last block to finish
         // reduce and solve in place of k_reduce_solve with device-scope fences -- every block then waits for an L2 write-back, 79 us
         // per pass instead of 27 + 12.)
@@ -922,18 +997,24 @@ __global__ __launch_bounds__(kPassThreads, ACC ? FUSED_WAVES : COMPACT_WAVES) vo
             nq[k] = make_float4(0.f, 0.f, 0.f, 2.0f);
             pa[k] = -1;
             if (i < a.n) {
-                x[k] = a.in.x[i]; y[k] = a.in.y[i]; z[k] = a.in.z[i];
                 if (ACC) {
-                    nx[k] = a.in.nx[i]; ny[k] = a.in.ny[i]; nz[k] = a.in.nz[i];
-                    q[k] = a.pairrec[2 * (size_t)i]; nq[k] = a.pairrec[2 * (size_t)i + 1];      // a fresh copy (w = 0) has the bits of tq[prev]
+                    const size_t o = (size_t)i;
+                    x[k] = gcol<float>(s_col[0])[o]; y[k] = gcol<float>(s_col[1])[o]; z[k] = gcol<float>(s_col[2])[o];
+                    nx[k] = gcol<float>(s_col[3])[o]; ny[k] = gcol<float>(s_col[4])[o]; nz[k] = gcol<float>(s_col[5])[o];
+                    q[k] = as_float4(gcol<f32x4_t>(s_col[6])[2 * o]); nq[k] = as_float4(gcol<f32x4_t>(s_col[6])[2 * o + 1]);      // a fresh copy (w = 0) has the bits of tq[prev]
+                    ce[k] = as_float4(gcol<f32x4_t>(s_col[7])[o]);
                 } else {
+                    x[k] = a.in.x[i]; y[k] = a.in.y[i]; z[k] = a.in.z[i];
                     pa[k] = a.pos_prev[i];
                     if ((uint32_t)pa[k] < ix.n) { q[k] = ix.tq[pa[k]]; nq[k].w = 0.0f; }
+                    ce[k] = a.cert[i];
                 }
-                ce[k] = a.cert[i];
             }
         }
         if (stop) return;                 // (uniform; nothing has been written yet)
+#ifdef RS_STAMPS2
+        if (fs1 == 0) fs1 = __builtin_amdgcn_s_memrealtime();       // loop state and the first tile's data are here
+#endif
 #pragma unroll
         for (uint32_t k = 0; k < kPpt; k++) {
             const uint32_t i = i0 + k * kPassThreads;
@@ -956,8 +1037,9 @@ __global__ __launch_bounds__(kPassThreads, ACC ? FUSED_WAVES : COMPACT_WAVES) vo
                     }
                 }
                 if (certified) {
-                    a.d2_out[i] = d2;                                  // refreshed distance of the (possibly changed) pair
-                    if (ACC) fused_accumulate(acc, a, X, nx[k], ny[k], nz[k], px, py, pz, q[k], nq[k], d2);
+                    if (ACC) gcol<float>(s_col[8])[i] = d2;            // refreshed distance of the (possibly changed) pair
+                    else a.d2_out[i] = d2;
+                    if (ACC) fused_accumulate(acc, h, nx[k], ny[k], nz[k], px, py, pz, q[k], nq[k], d2);
                 } else {
                     s_list[atomicAdd(&s_cnt, 1u)] = i;                 // (room for a whole tile: see the flush below)
                 }
@@ -974,7 +1056,16 @@ __global__ __launch_bounds__(kPassThreads, ACC ? FUSED_WAVES : COMPACT_WAVES) vo
     flush();
     // pairs that had to be searched (see cells_tile)
     if (threadIdx.x == 0 && s_total) atomicAdd(wl.work.counts + shard * kShardStride + 1, s_total);
+#ifdef RS_STAMPS2
+    const unsigned long long fs2 = __builtin_amdgcn_s_memrealtime();
+#endif
     if (ACC) acc_block_reduce_store(acc, a.partials, a.partial_cols ? a.partial_cols : gridDim.x);
+#ifdef RS_STAMPS2
+    if (ACC && blockIdx.x == 0 && threadIdx.x == 0) {
+        double *dbg = a.partials + (size_t)8191 * kNSum;
+        dbg[0] = (double)(fs1 - fs0); dbg[1] = (double)(fs2 - fs1); dbg[2] = (double)(__builtin_amdgcn_s_memrealtime() - fs2);
+    }
+#endif
 }
 
 // ---------------------------------------------------------------------------
@@ -1463,7 +1554,9 @@ __global__ __launch_bounds__(512) void k_reduce_solve(const double *__restrict__
     LoopRecord &r = ring[it % ring_len];
     for (int k = 0; k < 16; k++) { r.increment[k] = Xi[k]; r.X[k] = Xn[k]; }
     r.rcond = rc; r.status = st; r.solved = 1;
-#ifdef RS_STAMPS
+#ifdef RS_STAMPS2
+    r.sums[37] = partials[(size_t)8191 * kNSum]; r.sums[38] = partials[(size_t)8191 * kNSum + 1]; r.sums[39] = partials[(size_t)8191 * kNSum + 2];
+#elif defined(RS_STAMPS)
     r.sums[37] = (double)(ts1 - ts0) + 1e-4 * (double)(tsA - ts0); r.sums[38] = (double)(ts2 - ts1); r.sums[39] = (double)(__builtin_amdgcn_s_memrealtime() - ts2);      // 10 ns ticks: load + reduce, bookkeeping + solve, publish
 #endif
     if (cfg.eps_rotation > 0.f && cfg.eps_translation > 0.f && !cfg.fixed_iters) {
