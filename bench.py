@@ -308,11 +308,13 @@ def main():
             e["frac"] = round(e["achieved"] / VALU_PEAK_GINST, 4)
         act = k.get("valu_active_quad_cycles")
         if act and ms > 0:
-            # measured: share of the SIMDs' cycles with a vector instruction of some wave in flight (SQ_ACTIVE_INST_VALU quad-cycles x 4
-            # over SIMDs x duration x nominal clock).  The mix of these kernels (readlane, compares, selects, DPP, SGPR operands) issues at
-            # ~4 cycles per instruction, not the 2 of the peak above (scratch/ubench/valu_rates*.hip): this is the figure that says how
-            # much issue capacity is left
-            e["valu_busy_frac"] = round(act * 4.0 / (N_SIMD * ms * 1e-3 * CLOCK_GHZ * 1e9), 4)
+            # measured: per-wave cycles with a vector instruction in flight (SQ_ACTIVE_INST_VALU quad-cycles x 4), summed over waves, over
+            # SIMDs x live duration x nominal clock.  The mix of these kernels (readlane, compares, selects, DPP, SGPR operands) issues at
+            # ~4 cycles per instruction, not the 2 of the peak above (scratch/ubench/valu_rates*.hip): this says how much issue capacity
+            # is left.  An UPPER estimate of SIMD utilisation, not a utilisation: counter and duration come from different runs, the
+            # clock is nominal, and in-flight instructions of two waves of one SIMD overlap by their pipeline latency (C5 8M first
+            # pass: 1.09) -- so values near or above 1 mean "issue-bound", nothing finer
+            e["valu_inflight_over_simd_cycles"] = round(act * 4.0 / (N_SIMD * ms * 1e-3 * CLOCK_GHZ * 1e9), 4)
         return e
 
     if args.corr == "tree" and first_ms:
