@@ -47,6 +47,7 @@ void read_switches(Switches &w)
     w.compact_blocks = (int)num("SYMMICP_COMPACT_BLOCKS", 1280);
     w.tune.wave_mode_max = (uint32_t)num("SYMMICP_WAVE_MODE_MAX", 20000);
     w.tune.cells_chunk = (uint32_t)num("SYMMICP_CELLS_CHUNK", 16);
+    w.tune.cells_queries = (uint32_t)num("SYMMICP_CELLS_QUERIES", 0);
     w.tune.walk_budget = (uint32_t)num("SYMMICP_WALK_BUDGET", 160);
 }
 
@@ -733,6 +734,17 @@ int symmicp_get_correspondences(symmicp_ctx *c, int32_t *idx, float *d2, size_t 
         for (int k = 0; k < 12; k++) X.m[k] = m[k];
         X.nrm_w = 0.f;
         launch_identity_d2(incr ? c->cur : c->src0, X, c->tgt, c->src_off, c->n_loc, c->d2, c->stream);
+    }
+    if (mode == 2 && d2) {
+        // the tree passes store a distance only for the pairs they searched: evaluate all of them at the positions of the last pass
+        const bool incr = resolved_apply(c->cfg) == SYMMICP_APPLY_INCREMENTAL;
+        Affine X{};
+        float I[16];
+        identity16(I);
+        const float *m = incr ? I : c->X;
+        for (int k = 0; k < 12; k++) X.m[k] = m[k];
+        X.nrm_w = 0.f;
+        launch_pairs_d2(incr ? c->cur : c->src0, X, c->pos, c->tq, c->n_t, c->n_loc, c->d2, c->stream);
     }
     launch_corr_out(c->pos, c->best64, c->d2, c->tq, c->src_order, c->n_loc, mode, c->src_off, d_idx.p, d_d2.p, c->stream);
     if (idx) HIP_TRY(c, hipMemcpyAsync(idx, d_idx.p, sizeof(int32_t) * need, hipMemcpyDeviceToHost, c->stream));

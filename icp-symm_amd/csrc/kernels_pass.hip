@@ -465,9 +465,7 @@ __device__ __forceinline__ void cells_tile(const PassArgs &a, const TargetIndex 
                 }
             }
         }
-        if (certified) {
-            a.d2_out[i] = b.d2;          // same pair, refreshed distance; position, certificate unchanged
-        } else {
+        if (!certified) {               // (certified: same pair, nothing stored -- its distance is evaluated when someone asks: k_pairs_d2)
             uncert = true;
             defer = true;
             if (b.pos >= 0 && ix.glevel > 0) {
@@ -792,11 +790,15 @@ __device__ __forceinline__ void cells_tile(const PassArgs &a, const TargetIndex 
 }
 
 template <bool HOOD>
-__global__ __launch_bounds__(kPassThreads) void k_search_cells(PassArgs a, TargetIndex ix, WorkLists wl, uint32_t chunk)
+__global__ __launch_bounds__(kPassThreads) void k_search_cells(PassArgs a, TargetIndex ix, WorkLists wl, uint32_t chunk, uint32_t qshift)
 {
     // (tiles dealt to the XCDs in chunks of kCellsChunk: the regions of a cloud differ in cost, see xcd_remap_chunked; tiles past the end idle)
+    // A tile is 1 << qshift queries (256, 128 or 64) scanned by all 256 threads.  A workgroup lives as long as its chain of scan rounds
+    // (256 items each: three dependent gathers and a barrier): a share of 125 k queries (1M points over 8 ranks) is 488 tiles of 256 --
+    // under two per CU, and the launch lasts one workgroup's 15 rounds; tiles of 64 are four times as many workgroups of 4 rounds each.
     const uint32_t tile = xcd_remap_chunked(blockIdx.x, chunk);
-    cells_tile<HOOD>(a, ix, wl, a.X, tile * kPassThreads + threadIdx.x, tile & (kShards - 1), false);      // (the shard follows the tile: the lists' capacity assumes an even spread)
+    const uint32_t i = threadIdx.x < (1u << qshift) ? (tile << qshift) + threadIdx.x : 0xFFFFFFFFu;
+    cells_tile<HOOD>(a, ix, wl, a.X, i, tile & (kShards - 1), false);      // (the shard follows the tile: the lists' capacity assumes an even spread)
 }
 
 // ---------------------------------------------------------------------------
@@ -879,7 +881,7 @@ __global__ __launch_bounds__(kPassThreads, ACC ? FUSED_WAVES : COMPACT_WAVES) vo
     if (ACC && threadIdx.x == 0) {
         s_col[0] = (unsigned long long)a.in.x; s_col[1] = (unsigned long long)a.in.y; s_col[2] = (unsigned long long)a.in.z;
         s_col[3] = (unsigned long long)a.in.nx; s_col[4] = (unsigned long long)a.in.ny; s_col[5] = (unsigned long long)a.in.nz;
-        s_col[6] = (unsigned long long)a.pairrec; s_col[7] = (unsigned long long)a.cert; s_col[8] = (unsigned long long)a.d2_out;
+        s_col[6] = (unsigned long long)a.pairrec; s_col[7] = (unsigned long long)a.cert;
     }
     __syncthreads();
     int stop = 0;
@@ -937,7 +939,6 @@ __global__ __launch_bounds__(kPassThreads, ACC ? FUSED_WAVES : COMPACT_WAVES) vo
                 if (hood_test(a, ix, i, px, py, pz, dist2(px, py, pz, ce.x, ce.y, ce.z), pk, d2, __float_as_int(q.w), pw, d2w)) {
                     float4 qw = q, nqw = nq;
                     if (pw != pk) { qw = ix.tn[2 * (size_t)pw]; nqw = ix.tn[2 * (size_t)pw + 1]; }
-                    a.d2_out[i] = d2w;
                     const float nx = a.in.nx[i], ny = a.in.ny[i], nz = a.in.nz[i];
                     fused_accumulate(acc, h, nx, ny, nz, px, py, pz, qw, nqw, d2w);
                     s_list[e] = 0xFFFFFFFFu;                       // settled (an idle lane of the scan below)
@@ -1037,8 +1038,7 @@ __global__ __launch_bounds__(kPassThreads, ACC ? FUSED_WAVES : COMPACT_WAVES) vo
                     }
                 }
                 if (certified) {
-                    if (ACC) gcol<float>(s_col[8])[i] = d2;            // refreshed distance of the (possibly changed) pair
-                    else a.d2_out[i] = d2;
+                    // (the refreshed distance is not stored: 4 of the pass's 76 bytes per point; symmicp_get_correspondences evaluates it)
                     if (ACC) fused_accumulate(acc, h, nx[k], ny[k], nz[k], px, py, pz, q[k], nq[k], d2);
                 } else {
                     s_list[atomicAdd(&s_cnt, 1u)] = i;                 // (room for a whole tile: see the flush below)
@@ -1659,6 +1659,29 @@ __global__ __launch_bounds__(256) void k_identity_d2(CloudSoA in, Affine X, Clou
     d2[i] = dist2(px, py, pz, tgt.x[j], tgt.y[j], tgt.z[j]);
 }
 
+// TREE: the distance of every current pair, from the positions the last pass gave the queries.  The passes store a distance only where
+// they searched; a certified pair keeps its target, and the expression below is the one every kernel evaluates for it (same operations,
+// same order: the same bits).  No pair: +inf, as the searches store it.
+__global__ __launch_bounds__(256) void k_pairs_d2(CloudSoA in, Affine X, const int32_t *__restrict__ pos, const float4 *__restrict__ tq, uint32_t n_t, uint32_t n, float *d2)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int32_t p = pos[i];
+    float v = __int_as_float(0x7f800000);
+    if (p >= 0 && (uint32_t)p < n_t) {
+        const float x = in.x[i], y = in.y[i], z = in.z[i];
+        const float px = xf_row(X.m + 0, x, y, z, 1.0f), py = xf_row(X.m + 4, x, y, z, 1.0f), pz = xf_row(X.m + 8, x, y, z, 1.0f);
+        const float4 q = tq[p];
+        v = dist2(px, py, pz, q.x, q.y, q.z);
+    }
+    d2[i] = v;
+}
+
+void launch_pairs_d2(const CloudSoA &in, const Affine &X, const int32_t *pos, const float4 *tq, uint32_t n_t, uint32_t n, float *d2, hipStream_t s)
+{
+    if (n) hipLaunchKernelGGL(k_pairs_d2, dim3((n + 255) / 256), dim3(256), 0, s, in, X, pos, tq, n_t, n, d2);
+}
+
 void launch_identity_d2(const CloudSoA &in, const Affine &X, const CloudSoA &tgt, uint32_t tgt_offset, uint32_t n, float *d2, hipStream_t s)
 {
     hipLaunchKernelGGL(k_identity_d2, dim3((n + 255) / 256), dim3(256), 0, s, in, X, tgt, tgt_offset, n, d2);
@@ -1708,9 +1731,13 @@ void launch_pass_tree_split(const PassArgs &a_in, const TargetIndex &ix, const W
         if (compact_blocks > 0) hipLaunchKernelGGL(k_pass_fused<false>, dim3(min((uint32_t)compact_blocks, nbp)), dim3(kPassThreads), 0, s, a, ix, wl);
         else {
             const uint32_t chunk = tune.cells_chunk ? tune.cells_chunk : 16u;      // tiles per chunk
-            const uint32_t nbc = ((nb + 8u * chunk - 1u) / (8u * chunk)) * (8u * chunk);
-            if (a.make_hood) hipLaunchKernelGGL(k_search_cells<true>, dim3(nbc), dim3(kPassThreads), 0, s, a, ix, wl, chunk);
-            else hipLaunchKernelGGL(k_search_cells<false>, dim3(nbc), dim3(kPassThreads), 0, s, a, ix, wl, chunk);
+            // queries per tile: 256 while that fills the chip a few times over (256 CUs x 6-7 workgroups), else 128 or 64 (k_search_cells)
+            uint32_t qshift = nb >= 3072u ? 8u : (nb >= 1536u ? 7u : 6u);
+            if (tune.cells_queries == 64u) qshift = 6u; else if (tune.cells_queries == 128u) qshift = 7u; else if (tune.cells_queries == 256u) qshift = 8u;
+            const uint32_t nq = (a.n + (1u << qshift) - 1u) >> qshift;
+            const uint32_t nbc = ((nq + 8u * chunk - 1u) / (8u * chunk)) * (8u * chunk);
+            if (a.make_hood) hipLaunchKernelGGL(k_search_cells<true>, dim3(nbc), dim3(kPassThreads), 0, s, a, ix, wl, chunk, qshift);
+            else hipLaunchKernelGGL(k_search_cells<false>, dim3(nbc), dim3(kPassThreads), 0, s, a, ix, wl, chunk, qshift);
         }
     }
     if (ev) hipEventRecord(ev[1], s);

@@ -158,6 +158,7 @@ struct PassArgs {
 struct PassTuning {
     uint32_t wave_mode_max = 20000u;    // work lists longer than this use one thread per query (the 48k-entry list after the first move of the 1M surface pair: 115 -> 85 us)
     uint32_t cells_chunk = 16u;         // tiles per XCD chunk of k_search_cells
+    uint32_t cells_queries = 0u;        // queries per tile of k_search_cells (64, 128, 256; 0: from the share's size)
     uint32_t walk_budget = 160u;        // node visits of the budgeted walk (sharded first passes on volume-like targets)
 };
 
@@ -224,6 +225,7 @@ void launch_corr_out(const int32_t *pos, const unsigned long long *best64, const
                      hipStream_t s);
 
 void launch_identity_d2(const CloudSoA &in, const Affine &X, const CloudSoA &tgt, uint32_t tgt_offset, uint32_t n, float *d2, hipStream_t s);
+void launch_pairs_d2(const CloudSoA &in, const Affine &X, const int32_t *pos, const float4 *tq, uint32_t n_t, uint32_t n, float *d2, hipStream_t s);
 void launch_normals_knn(const TargetIndex &ix, int k, const float vp[3], float *nrm_out, float *curv_out, hipStream_t s);
 
 }  // namespace symmicp

@@ -949,6 +949,20 @@ def test_first_pass_regimes_forced_in_a_subprocess(sym, regime):
     assert " passed" in r.stdout
 
 
+@pytest.mark.parametrize("queries", ["128", "256"])
+def test_cell_scan_tile_sizes_forced_in_a_subprocess(sym, queries):
+    """k_search_cells scans tiles of 64, 128 or 256 queries with its 256 threads, chosen from the share's size (small shares: more,
+    shorter workgroups).  The clouds of this suite are small (tiles of 64 by default): SYMMICP_CELLS_QUERIES forces the other two
+    sizes on the multi-pass exactness tests -- pairs and distances bit-exact against the oracle after every pass."""
+    import subprocess
+    env = dict(os.environ, SYMMICP_CELLS_QUERIES=queries)
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
+                        "-k", "tree_follows_previous_pairs or randomised_exactness or pair_certificates or partial_overlap or sharded_ranks or lattice"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout
+
+
 def test_pair_certificates_stay_exact_under_small_and_large_moves(sym, oracle):
     """Pair certificates (k_search_cells): after a search a pair is re-used while the query has provably not
     moved far enough to change its nearest neighbour.  Drive the engine with a sequence of tiny and not-so-tiny
