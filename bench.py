@@ -324,7 +324,7 @@ def main():
                                       sum(second_third) / len(second_third), "search_pass"))
         if converged_ms:
             fused = passes["loop"] == "device"
-            b = n_loc * (76 if fused else 108)      # fused: p 12 + n 12 + record copy 32 + certificate 16 + d2 4; split: cells 52 + accumulate 56
+            b = n_loc * (72 if fused else 104)      # fused: p 12 + n 12 + record copy 32 + certificate 16 (a certified pair stores nothing); split: cells 48 + accumulate 56
             a = b / (converged_ms * 1e-3) / 1e9
             e = dict(regime="converged passes (pairs certified: the pass is a stream)", kernel="k_pass_fused<true>" if fused else "k_search_cells+k_accumulate",
                      ms=round(converged_ms, 5), bound="hbm", unit="GB/s", peak=HBM_PEAK_GBS, achieved=round(a, 1), frac=round(a / HBM_PEAK_GBS, 4),
