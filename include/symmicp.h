@@ -159,7 +159,8 @@ int symmicp_get_transform(const symmicp_ctx *ctx, float out16[16]);           /*
 size_t symmicp_format_result(const float transform16[16], char *buf, size_t cap);
 int symmicp_get_pivot(const symmicp_ctx *ctx, float out3[3]);
 /* current pairs in ORIGINAL numbering: idx[i] = target row paired with source row i
- * (rows of this rank's share; -1 = rejected), d2[i] = squared distance. Either may be NULL. */
+ * (rows of this rank's share; -1 = rejected), d2[i] = squared distance. Either may be NULL.  (SYMMICP_CORR_IDENTITY and _TREE evaluate
+ * the distances here, at the positions the last pass gave the points: a pass stores them only for the pairs it searched.) */
 int symmicp_get_correspondences(symmicp_ctx *ctx, int32_t *idx, float *d2, size_t cap);
 /* current (transformed) source points / normals of this rank's share, original row order, packed AoS. */
 int symmicp_get_source(symmicp_ctx *ctx, float *xyz, float *nrm, size_t cap);
