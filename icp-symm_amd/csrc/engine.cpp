@@ -30,6 +30,7 @@ void read_switches(Switches &w)
     w.packet_lds_pad = (uint32_t)num("SYMMICP_PACKET_LDS_PAD", 0);
     w.packet_waves = (uint32_t)num("SYMMICP_PACKET_WAVES", 0);
     w.packet_front_cap = (uint32_t)num("SYMMICP_PACKET_FRONT_CAP", 0);
+    if (const char *e = std::getenv("SYMMICP_HOOD_FRAC")) w.hood_frac = std::atof(e);
     w.no_hood = flag("SYMMICP_NO_NEIGHBOURHOOD");
     w.no_cert = flag("SYMMICP_NO_CERT");
     w.walk_full_grid = flag("SYMMICP_WALK_FULL_GRID");

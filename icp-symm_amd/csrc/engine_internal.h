@@ -89,6 +89,7 @@ struct Switches {
     float packet_jump = -1.0f;             // cut factor of k_packet_runs (< 0: the default, 0: never cut)
     int packet_key_bits = 16;
     uint32_t packet_chunk = 0, packet_lds_pad = 0, packet_waves = 0, packet_front_cap = 0;
+    double hood_frac = 0.8;                // scans keep neighbourhoods once the previous pass searched under this fraction of the pairs
     bool no_hood = false, no_cert = false, walk_full_grid = false, host_loop = false, no_loop_stragglers = false, force_comm = false;
     int budget_walk = -1, optimistic = -1, compact = -1;      // -1 auto, 0 never, 1 always
     int pass_blocks = 2048, id_blocks = 2048, acc_blocks = 512, fused_blocks = 512, compact_blocks = 1280;

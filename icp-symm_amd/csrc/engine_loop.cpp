@@ -28,8 +28,9 @@ static void fill_pass_args(symmicp_ctx *c, PassArgs &a, const float Xapply[16], 
     a.cert = reinterpret_cast<float4 *>(c->cert);
     a.certk = c->sw.no_hood ? nullptr : reinterpret_cast<uint4 *>(c->certk);
     a.hoodr = reinterpret_cast<float2 *>(c->hoodr);
-    // neighbourhoods are worth their stores once the alignment is settling (the previous pass searched under half of the pairs)
-    a.make_hood = (a.certk && !first && c->last_uncertified >= 0 && c->last_uncertified < (long long)(c->n_s_total / 2)) ? 1 : 0;
+    // neighbourhoods are worth their stores once the alignment is settling (the previous pass searched under 80 % of the pairs: 8M scan pair
+    // 2 680 iter/s at 50 %, 2 776 at 80 %, 2 742 always; 1M surface pair 16 050 / 15 960 / 15 700)
+    a.make_hood = (a.certk && !first && c->last_uncertified >= 0 && (double)c->last_uncertified < c->sw.hood_frac * (double)c->n_s_total) ? 1 : 0;
     a.pairrec = c->pairrec;
     // sharded runs: the first pass over a small share is bound by its slowest walks, not by throughput
     a.budget_walk = c->sw.budget_walk >= 0 ? c->sw.budget_walk : (first && c->nranks > 1 && c->n_loc < 400000u);      // (SYMMICP_BUDGET_WALK: "0" never, "1" always)
@@ -381,7 +382,12 @@ static int run_batch(symmicp_ctx *c, int want, float *diffs_before, int *n_done,
             stragglers = false;
             for (int k = it_before + 1; k <= c->h_loop->iters; k++) stragglers = stragglers || c->h_ring[k % symmicp_ctx::kRing].list_len > 0;
         }
-        chunk *= 2;
+        // with the stage on, chunks stay short: the stage (two more launches per pass) can only be dropped between chunks, and lists die out
+        // within a few passes of a run's start (8M scan pair: 8 8 6 2 | 2 0 1 0 | 0 ...); once it is off and only a bail-out can stop the run,
+        // the rest goes out in one piece
+        if (stragglers) chunk = 4;
+        else if (lc.fixed_iters && !(lc.eps_rotation > 0.f && lc.eps_translation > 0.f)) chunk = want;
+        else chunk *= 2;
     }
     const LoopState &hl = *c->h_loop;
     const int it1 = hl.iters;                         // passes complete
@@ -404,6 +410,11 @@ static int run_batch(symmicp_ctx *c, int want, float *diffs_before, int *n_done,
     if (c->sw.debug_host && it1 - it0 >= 2) {      // (a library built with -DRS_STAMPS leaves k_reduce_solve's phase durations in the spare slots of each record)
         const double *q = c->h_ring[(it1 - 1) % symmicp_ctx::kRing].sums;
         if (q[37] != 0.0) std::fprintf(stderr, "[symmicp host] k_reduce_solve stamps of pass %d: load + reduce %.2f us (loop state there after %.2f us), bookkeeping + solve %.2f us, publish %.2f us\n", it1 - 1, std::floor(q[37]) * 0.01, (q[37] - std::floor(q[37])) * 1e4 * 0.01, q[38] * 0.01, q[39] * 0.01);
+    }
+    if (c->sw.debug_host && tree) {
+        std::fprintf(stderr, "[symmicp host] batch: work list / searched pairs after each device pass:");
+        for (int k = it0 + 1; k <= it1; k++) std::fprintf(stderr, " %d/%d", c->h_ring[k % symmicp_ctx::kRing].list_len, c->h_ring[k % symmicp_ctx::kRing].pad);
+        std::fprintf(stderr, "\n");
     }
     if (c->sw.debug_host) std::fprintf(stderr, "[symmicp host] batch: %d of %d passes on the device (%d enqueued), reason %d, %d with the straggler stage, list after %lld\n", it1 - it0, want, enq, hl.reason, n_stage, (long long)c->last_list_len);
     if (hl.reason == LOOP_SLOW) c->host_passes_since_bailout = 1;      // one host pass, then look again
