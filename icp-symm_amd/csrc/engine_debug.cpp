@@ -23,8 +23,8 @@ void print_pass_counters(symmicp_ctx *c, bool first, long long list_len)
         hipMemcpy(h, c->ix.dbg, sizeof(h), hipMemcpyDeviceToHost);
         hipMemset(c->ix.dbg, 0, sizeof(h));
         if (first && c->cfg.corr == SYMMICP_CORR_TREE && c->target_surface_like)
-            std::fprintf(stderr, "[symmicp dbg] pass %lld (packets): steps=%llu nodes+leaf candidates=%llu leaf candidates rejected=%llu points=%llu tie rescans=%llu overflows=%llu | packet ticks (10 ns): sum=%llu max=%llu\n",
-                         (long long)c->st.passes, h[0], h[4], h[5], h[3], h[2], h[1], h[7], h[6]);
+            std::fprintf(stderr, "[symmicp dbg] pass %lld (packets): steps=%llu nodes+leaf candidates=%llu leaf candidates rejected=%llu points=%llu tie rescans=%llu overflows=%llu lanes wanting a scanned leaf (sum)=%llu | packet ticks (10 ns): sum=%llu max=%llu\n",
+                         (long long)c->st.passes, h[0], h[4], h[5], h[3], h[2], h[1], h[8], h[7], h[6]);
         else
         std::fprintf(stderr, "[symmicp dbg] pass %lld: cells: certified=%llu (by neighbourhood %llu) scans=%llu (neighbourhoods kept %llu, not kept %llu) probes=%llu to-walk=%llu items=%llu points=%llu | walk list=%lld visits=%llu wave-max*64=%llu\n",
                      (long long)c->st.passes, h[1], h[8], h[2], h[9], h[10], h[6], h[7], h[0], h[3], list_len, h[4], h[5]);

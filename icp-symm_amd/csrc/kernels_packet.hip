@@ -169,7 +169,7 @@ __device__ __forceinline__ float bcast(float v, int src_lane)
 // wants it -> next pop; leaf -> scan; internal -> lane 4c+g tests child c against sub-group g's box and bound, the
 // children some sub-group may need are pushed, the nearest on top.  Exact for any starting bounds.
 struct PktCounters {
-    unsigned long long nodes, leaves, rejected, points, ties, steps, overflow;
+    unsigned long long nodes, leaves, rejected, points, ties, steps, overflow, wantlanes;
 };
 
 template <bool CERT>
@@ -304,7 +304,9 @@ __device__ __forceinline__ bool pkt_step(const uint32_t *fr_cur, uint32_t *fr_ne
             float4 lo, hi;
             lo.x = bcast(cA.x, src); lo.y = bcast(cA.y, src); lo.z = bcast(cA.z, src);
             hi.x = bcast(cB.x, src); hi.y = bcast(cB.y, src); hi.z = bcast(cB.z, src);
-            if (__ballot(boxdist2(px, py, pz, lo, hi) <= thr) == 0ull) { if (DBG) cn.rejected++; continue; }
+            const unsigned long long mw = __ballot(boxdist2(px, py, pz, lo, hi) <= thr);
+            if (mw == 0ull) { if (DBG) cn.rejected++; continue; }
+            if (DBG) cn.wantlanes += (unsigned long long)__popcll(mw);
             const uint32_t cnt = oct_cf((uint32_t)__builtin_amdgcn_readlane((int)cpk, src));
             if (DBG) cn.points += cnt;
             // the leaf's points come through the scalar cache, 8 at a time (one dependent round trip per 8 points, hidden by the other waves of the
@@ -375,7 +377,7 @@ __global__ __launch_bounds__(64 * W, W == 1 ? PKT_WAVES1 : PKT_WAVESN) void k_se
     const float pad = 0.0f;
     const float4 *__restrict__ tq = ix.tq;
     const float4 *__restrict__ onodes = ix.onodes;
-    PktCounters cn = {0, 0, 0, 0, 0, 0, 0};
+    PktCounters cn = {0, 0, 0, 0, 0, 0, 0, 0};
     for (uint32_t slot = xcd_remap_chunked(blockIdx.x, chunk); slot < npk; slot += gridDim.x) {
         // a packet: `count` consecutive queries from `first` (the table: widest first), or 64 as they lie
         uint32_t first = slot * 64u, count = 64u;
@@ -501,7 +503,7 @@ __global__ __launch_bounds__(64 * W, W == 1 ? PKT_WAVES1 : PKT_WAVESN) void k_se
                     // every bound update of the sweep above a scratch store; that was most of the 217 MB the round-2 kernel wrote per launch)
                     PktBest b2 = b;
                     float thr2 = thr;
-                    PktCounters cn2 = {0, 0, 0, 0, 0, 0, 0};
+                    PktCounters cn2 = {0, 0, 0, 0, 0, 0, 0, 0};
                     pkt_dfs<CERT>(onodes, tq, s_off, s_buf, s_sb, s_lvl, lane, px, py, pz, b2, thr2, pad, cn2);
                     b = b2; thr = thr2;
                     if (DBG) { cn.nodes += cn2.nodes; cn.leaves += cn2.leaves; cn.rejected += cn2.rejected; cn.points += cn2.points; cn.ties += cn2.ties; }
@@ -553,6 +555,7 @@ __global__ __launch_bounds__(64 * W, W == 1 ? PKT_WAVES1 : PKT_WAVESN) void k_se
         atomicAdd(ix.dbg + 3, cn.points);
         atomicAdd(ix.dbg + 4, cn.nodes + cn.leaves);
         atomicAdd(ix.dbg + 5, cn.rejected);
+        atomicAdd(ix.dbg + 8, cn.wantlanes);
     }
 }
 
