@@ -816,7 +816,7 @@ __global__ __launch_bounds__(kPassThreads) void k_search_cells(PassArgs a, Targe
 // separate kernels).  The transform comes from the device-resident loop state when there is one (a.loop): passes can be
 // enqueued back to back without the host (k_reduce_solve writes the next transform); a stopped loop returns at once.
 // ---------------------------------------------------------------------------
-constexpr int kFusedList = 2048;      // (>= two tiles of the fused pass: a tile is 1024 points there)
+constexpr int kFusedList = 2048;      // (room for the uncertified points of several 256-point tiles between two flushes)
 
 // What the streaming loop of k_pass_fused needs of its arguments, held in VECTOR registers.  The kernel's three argument structs are ~150
 // scalars, all live across the loop (the scan behind it needs them); with 102 scalar registers per wave the compiler parked them in the
@@ -970,9 +970,9 @@ __global__ __launch_bounds__(kPassThreads, ACC ? FUSED_WAVES : COMPACT_WAVES) vo
         __syncthreads();
     };
 
-    // A tile = kPpt x 256 consecutive points; a thread takes the points tid, tid + 256, ... of its tile (every load coalesced).  ACC: 4 points
-    // per thread -- all 4 x (6 columns + 2 x 16 B record copy + 16 B certificate) = 288 B per lane are requested before the first is
-    // used: with one point per thread (76 B per lane in flight, 2 waves per SIMD) the pass moved its bytes at 3.0 TB/s (25 us at 1M points)
+    // A tile = kPpt x 256 consecutive points; a thread takes the points tid, tid + 256, ... of its tile (every load coalesced).  kPpt = 1:
+    // 2 and 4 points per thread with everything requested up front (144 / 288 B per lane in flight instead of 72) were measured in rounds 2
+    // and 3 and are no faster at any size: the loop is bound by its arithmetic and one round trip per tile, not by bytes in flight
     constexpr uint32_t kPpt = ACC ? FUSED_PPT : 1u;
     constexpr uint32_t kTilePts = kPpt * kPassThreads;
     const uint32_t tiles = (a.n + kTilePts - 1) / kTilePts;
