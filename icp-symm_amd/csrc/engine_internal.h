@@ -80,7 +80,7 @@ inline double now_s()
 struct Switches {
     bool allow_any_arch = false, debug_host = false, debug_counters = false;
     std::string debug_trace;               // per-packet trace file of the first pass ("" = off)
-    double grid_ppc = 2.0;                 // points per occupied cell the grid level is chosen for
+    double grid_ppc = 3.0;                 // points per occupied cell the grid level is chosen for (2.0 until the end of round 3: one level finer on the surface pairs -- 15 (query, cell) items of ~1 point per probe instead of 8 of ~4; 1M pair 12 740 -> 13 230 iter/s at 20 iterations, 250k / 4M +3 %, scan pairs and the 100k cube unchanged)
     int grid_maxlevel = kMortonBits, grid_level = -1;      // -1: chosen from the cloud; 0 disables the grid phase
     int first_pass = -1;                   // -1: decided per target (build_index); 0: per-thread walk; 1: packets
     int oct_leaf = 0;                      // octree leaf size (0: 16 on surface-like targets, 8 otherwise)
