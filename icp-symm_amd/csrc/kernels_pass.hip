@@ -345,7 +345,13 @@ __device__ __forceinline__ float axis_gap2(float p, float origin, int c, float h
 // T follows the local point spacing: a scan counts ALL points within its T, kept or not, and leaves hint = T (6.5 / count)^0.4 for the
 // pair's next scan (the count grows with T^2 on a surface, T^3 in a noisy slab); a first scan starts from 2 x the previous pair's
 // distance.
-constexpr float kSlackFrac = 0.25f;      // (0.125 / 0.5 / 1.0 measured on the 1M surface pair and the 2M scan pair: within noise or worse)
+#ifndef SLACK_FRAC
+#define SLACK_FRAC 0.0625f
+#endif
+// (with the grid at ~4 points per cell: 0.5 / 0.25 / 0.125 / 0.0625 / 0.031 / 0.016 of a cell edge give pass 3 of the 1M surface pair in
+// 0.240 / 0.178 / 0.153 / 0.139 / 0.135 / 0.128 ms; the 8M scan pair holds 2 780 iter/s down to 0.0625 and drops to 2 645 / 2 543 below:
+// its settling passes want some room.  At ~1 point per cell, rounds 1-2, 0.125 .. 1.0 were within noise.)
+constexpr float kSlackFrac = SLACK_FRAC;
 constexpr int kHoodSlots = 8;            // |S| <= 8, the winner included
 constexpr uint32_t kHoodNone = 0xFFFFFFFFu;
 
