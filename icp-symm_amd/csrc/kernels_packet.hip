@@ -566,7 +566,7 @@ __global__ __launch_bounds__(64 * W, W == 1 ? PKT_WAVES1 : PKT_WAVESN) void k_se
 // what a launch with few packets per GPU (a rank's share) lasts as long as -- so a block is cut into runs at its (up to 3) jumps: steps
 // between consecutive queries longer than kJumpFactor x the block's own scale (the smallest radius of its four groups of 16).
 // Per run: (first, count) into `runs`, key = descending squared radius (top key_bits bits), value = its index in `runs`.
-constexpr float kJumpFactor = 5.0f;        // (3: 0.60 ms, 5: 0.55, 6: 0.56, 8-10: 0.59, never: 0.655 on the 1M surface pair)
+constexpr float kJumpFactor = 4.5f;        // (round 2: 3: 0.60 ms, 5: 0.55, 6: 0.56, 8-10: 0.59, never: 0.655 on the 1M surface pair; end of round 3: 3 / 4 / 4.5 / 5 / 5.5 / never: 0.446 / 0.395 / 0.394 / 0.390 / 0.492 / 0.479 -- flat between 4 and 5 with a cliff right behind 5, hence 4.5)
 // A block whose four groups of 16 ALL straddle jumps has no small group to take its scale from, and with three cuts at most a block with
 // more jumps kept runs hundreds of point spacings wide: the first blocks of a rank's share (a thin strip of the cloud, crossed by the
 // Morton curve again and again) were such -- two packets per share of the 8-way split 1M pair overflowed their frontier and finished
